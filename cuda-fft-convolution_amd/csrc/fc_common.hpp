@@ -1,0 +1,70 @@
+// fc_common.hpp -- shared host/device definitions for the FFT-convolution engine.
+//
+// Everything in the *.hpp files of this directory is written once and compiled twice:
+//   - by hipcc for gfx950 (the product: kernels.hip -> libfftconv.so), and
+//   - by g++ for the host inside tests/emu (a test-only executor that runs the very same
+//     workgroup bodies sequentially so the algorithm can be checked without a GPU).
+// The host build is test infrastructure; the product library contains no CPU compute path.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define FC_HD __host__ __device__ __forceinline__
+#define FC_D __device__ __forceinline__
+#else
+#define FC_HD inline
+#define FC_D inline
+#endif
+
+namespace fc {
+
+struct alignas(8) c32 {
+    float x, y;
+};
+
+FC_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+FC_HD c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
+FC_HD c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+FC_HD c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+FC_HD c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+FC_HD c32 conj(c32 a) { return mk(a.x, -a.y); }
+FC_HD c32 scale(c32 a, float s) { return mk(a.x * s, a.y * s); }
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [0, N).
+template <int I>
+struct IC {
+    static constexpr int value = I;
+    constexpr operator int() const { return I; }
+};
+template <int B, int E, class F>
+FC_HD void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+constexpr int FC_MAX_STAGES = 12;
+
+// One stage of the in-place mixed-radix transform (see fft_lds.hpp).
+struct StageDesc {
+    int R;       // radix
+    int m;       // sub-length: the stage works on blocks of n = R*m elements
+    int tw_off;  // offset (in c32) of this stage's twiddles in the plan's table; -1 if m == 1
+};
+
+struct FftDesc {
+    int L;   // transform length = product of radices
+    int ns;  // number of stages
+    StageDesc st[FC_MAX_STAGES];
+};
+
+// Entry of the real<->half-complex pair table (see kernels_body.hpp).
+struct alignas(16) PairEntry {
+    int a;  // LDS position of bin k
+    int b;  // LDS position of bin M-k
+    c32 w;  // exp(-2*pi*i*k/N), N = 2M
+};
+
+}  // namespace fc

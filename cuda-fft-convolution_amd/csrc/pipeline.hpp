@@ -1,0 +1,132 @@
+// pipeline.hpp -- geometry of one plan and the argument blocks of its kernels.
+// Host-only, shared by the product library (fftconv_api.cpp) and the test-only emulator so
+// that both drive the workgroup bodies with identical arguments.
+#pragma once
+#include <algorithm>
+#include <cstddef>
+
+#include "kernels_body.hpp"
+#include "planner.hpp"
+
+namespace fc {
+
+constexpr size_t FC_LDS_BUDGET = 160 * 1024;  // bytes of LDS one workgroup may claim (gfx950 CU)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Geometry {
+    // problem (src/cudaConvolutionFFT.cu:92-112)
+    int H = 0, W = 0, F = 0;
+    int max_kh = 0, max_kw = 0;
+    int fft_h = 0, fft_w = 0;  // output window: computeFFTsize16(DATA + MAXK - 1)
+    // internal transform
+    int Lh = 0, Lw = 0;        // transform lengths (Lh even)
+    int M = 0;                 // Lh / 2
+    int rows = 0;              // M + 1 spectrum rows
+    int s_pitch = 0;           // c32 per image-spectrum row
+    int y_pitch = 0;           // c32 per intermediate row
+    int wout = 0;              // columns of Y consumed by the output pass: min(Lw, fft_w)
+    int lds_pitch = 0;         // c32 per LDS-resident column
+    int T_cols = 1;            // columns per workgroup in the h-passes
+    bool exact_window = false; // Lh == fft_h && Lw == fft_w: circular modulus equals the reference's
+    size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
+    size_t y_elems_per_kernel() const { return (size_t)rows * y_pitch; }
+    size_t map_elems() const { return (size_t)fft_h * fft_w; }
+};
+
+struct Tables {
+    Plan1D pm;  // M-point complex transform (h direction)
+    Plan1D pw;  // Lw-point complex transform (w direction)
+    std::vector<PairEntry> pairs;
+};
+
+// returns false if the sizes are invalid / unsupported
+inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw) {
+    if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
+    g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
+    g.fft_h = fft_size16(H + max_kh - 1);
+    g.fft_w = fft_size16(W + max_kw - 1);
+    g.Lh = choose_length(H + max_kh - 1, true, g.fft_h);
+    g.Lw = choose_length(W + max_kw - 1, false, g.fft_w);
+    if (g.Lh < 2 || g.Lw < 1) return false;
+    g.M = g.Lh / 2;
+    g.rows = g.M + 1;
+    g.s_pitch = round_up(g.Lw, 8);
+    g.wout = std::min(g.Lw, g.fft_w);
+    g.y_pitch = round_up(g.wout, 8);
+    g.lds_pitch = lds_col_pitch(g.M);
+    g.T_cols = 8;
+    while (g.T_cols > 1 && (size_t)g.T_cols * g.lds_pitch * sizeof(c32) > FC_LDS_BUDGET) g.T_cols /= 2;
+    if ((size_t)g.T_cols * g.lds_pitch * sizeof(c32) > FC_LDS_BUDGET) return false;
+    size_t row_lds = (size_t)g.Lw * sizeof(c32) * (F > 1 ? 2 : 1);
+    if (row_lds > FC_LDS_BUDGET) return false;
+    g.exact_window = (g.Lh == g.fft_h && g.Lw == g.fft_w);
+    t.pm = make_plan1d(g.M);
+    t.pw = make_plan1d(g.Lw);
+    t.pairs = make_pair_table(t.pm);
+    return true;
+}
+
+// Device-resident copies of the tables (pointers valid on whichever side runs the bodies).
+struct DeviceTables {
+    const c32* tw_m = nullptr;
+    const c32* tw_w = nullptr;
+    const PairEntry* pairs = nullptr;
+};
+
+// image columns: planes = F, columns = W, valid samples = H
+inline ColsR2CArgs image_cols_args(const Geometry& g, const Tables& t, const DeviceTables& d,
+                                   const float* image, c32* S) {
+    ColsR2CArgs a{};
+    a.in = image; a.in_plane_stride = (size_t)g.H * g.W; a.in_col_pitch = g.H; a.h_in = g.H; a.ncols = g.W;
+    a.out = S; a.out_plane_stride = (size_t)g.rows * g.s_pitch; a.out_pitch = g.s_pitch;
+    a.M = g.M; a.T = g.T_cols; a.lds_pitch = g.lds_pitch;
+    a.fd = t.pm.desc; a.tw = d.tw_m; a.pairs = d.pairs; a.npairs = (int)t.pairs.size();
+    return a;
+}
+
+inline RowsFwdArgs image_rows_args(const Geometry& g, const Tables& t, const DeviceTables& d, c32* S) {
+    RowsFwdArgs a{};
+    a.S = S; a.pitch = g.s_pitch; a.nvalid = g.W;
+    a.scale = (float)(1.0 / ((double)g.Lh * (double)g.Lw));
+    a.fd = t.pw.desc; a.tw = d.tw_w;
+    return a;
+}
+
+// kernel columns of a group of same-sized kernels, packed [n][f][kw][kh]: planes = nk*F
+inline int a_pitch_for(int kw) { return round_up(kw, 8); }
+
+inline ColsR2CArgs kernel_cols_args(const Geometry& g, const Tables& t, const DeviceTables& d,
+                                    const float* kernels, int kh, int kw, c32* A) {
+    ColsR2CArgs a{};
+    a.in = kernels; a.in_plane_stride = (size_t)kh * kw; a.in_col_pitch = kh; a.h_in = kh; a.ncols = kw;
+    a.out = A; a.out_plane_stride = (size_t)g.rows * a_pitch_for(kw); a.out_pitch = a_pitch_for(kw);
+    a.M = g.M; a.T = g.T_cols; a.lds_pitch = g.lds_pitch;
+    a.fd = t.pm.desc; a.tw = d.tw_m; a.pairs = d.pairs; a.npairs = (int)t.pairs.size();
+    return a;
+}
+
+inline SpectralRowsArgs spectral_rows_args(const Geometry& g, const Tables& t, const DeviceTables& d,
+                                           const c32* A, int kw, const c32* S, c32* Y) {
+    SpectralRowsArgs a{};
+    a.A = A; a.a_pitch = a_pitch_for(kw); a.a_feat_stride = (size_t)g.rows * a.a_pitch;
+    a.a_kernel_stride = (size_t)g.F * a.a_feat_stride; a.kw = kw;
+    a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
+    a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
+    a.F = g.F; a.fd = t.pw.desc; a.tw = d.tw_w;
+    return a;
+}
+
+inline ColsC2RArgs cols_c2r_args(const Geometry& g, const Tables& t, const DeviceTables& d,
+                                 const c32* Y, float* out, size_t out_kernel_stride) {
+    ColsC2RArgs a{};
+    a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wvalid = g.wout;
+    a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
+    a.M = g.M; a.T = g.T_cols; a.lds_pitch = g.lds_pitch;
+    a.fd = t.pm.desc; a.tw = d.tw_m; a.pairs = d.pairs; a.npairs = (int)t.pairs.size();
+    return a;
+}
+
+inline int tiles_for(int ncols, int T) { return (ncols + T - 1) / T; }
+
+}  // namespace fc

@@ -1,0 +1,180 @@
+// planner.hpp -- host-side planning: transform lengths, radix sequences, twiddle / digit-reversal
+// / real<->half-complex pair tables.  Header-only, host code only (used by the product library
+// and by the test-only emulator).
+//
+// Sizing contract (reference: src/cudaConvFFTData.h:96-102 computeFFTsize16,
+// src/cudaConvolutionFFT.cu:103-112): the OUTPUT window is FFT_X = ceil16(DATA_X + MAXK_X - 1).
+// The INTERNAL transform length L_X only has to satisfy L_X >= DATA_X + MAXK_X - 1 (linear
+// convolution support); it is chosen as the cheapest length that factors into the supported
+// radices.  When L_X == FFT_X (true for every BASELINE config) the engine computes exactly the
+// reference's circular convolution modulo FFT_X.
+#pragma once
+#include <cmath>
+#include <vector>
+
+#include "fc_common.hpp"
+#include "fft_lds.hpp"
+
+namespace fc {
+
+inline int fft_size16(int n) {  // src/cudaConvFFTData.h:96-102
+    int mod = n / 16, rem = n % 16;
+    return mod * 16 + (rem > 0 ? 16 : 0);
+}
+
+// Relative cost of one stage of radix R per element (butterfly + twiddle + LDS round trip).
+inline double radix_cost(int R) {
+    switch (R) {
+        case 2: return 13.0;
+        case 3: return 14.0;
+        case 4: return 14.0;
+        case 5: return 16.5;
+        case 7: return 18.5;
+        case 8: return 16.0;
+        case 11: return 22.5;
+        case 13: return 25.0;
+        case 16: return 21.0;
+        case 17: return 29.0;
+        default: return 1e9;
+    }
+}
+
+// Radix sequence (stage order) for length L, or empty if L has a prime factor > 17.
+// Even radices first, largest first; odd radices after, ascending.
+inline std::vector<int> factorize(int L) {
+    std::vector<int> r;
+    if (L < 1) return r;
+    if (L == 1) return r;
+    int e = 0, m = L;
+    while (m % 2 == 0) { m /= 2; e++; }
+    int a = e / 4, rem = e % 4;
+    if (rem == 1 && a >= 1) {  // 16^(a-1) * 8 * 4
+        for (int i = 0; i < a - 1; i++) r.push_back(16);
+        r.push_back(8);
+        r.push_back(4);
+    } else {
+        for (int i = 0; i < a; i++) r.push_back(16);
+        if (rem == 3) r.push_back(8);
+        if (rem == 2) r.push_back(4);
+        if (rem == 1) r.push_back(2);
+    }
+    const int odd[] = {3, 5, 7, 11, 13, 17};
+    for (int p : odd)
+        while (m % p == 0) { r.push_back(p); m /= p; }
+    if (m != 1) r.clear();
+    if (m != 1 || (int)r.size() > FC_MAX_STAGES) return std::vector<int>();
+    return r;
+}
+
+inline bool length_supported(int L) { return L == 1 || !factorize(L).empty(); }
+
+inline double length_cost(int L, bool real_half) {
+    // real_half: the transform actually run is complex of length L/2 (+ pair pass)
+    int Lc = real_half ? L / 2 : L;
+    std::vector<int> r = factorize(Lc);
+    if (Lc != 1 && r.empty()) return 1e30;
+    double c = 40.0 + (real_half ? 10.0 : 0.0);
+    for (int x : r) c += radix_cost(x) * (real_half ? 0.5 : 1.0);
+    return c * (double)L;
+}
+
+// Cheapest supported length >= need (even if real_half).  `exact` (>= need, e.g. the ceil16
+// window) wins ties and is preferred when within 2 % of the optimum, so that the common case
+// reproduces the reference's circular-convolution modulus exactly.
+inline int choose_length(int need, bool real_half, int exact) {
+    if (need < 1) need = 1;
+    int best = -1;
+    double bc = 1e30;
+    int hi = 2 * need + 32;
+    for (int L = need; L <= hi; L++) {
+        if (real_half && (L & 1)) continue;
+        double c = length_cost(L, real_half);
+        if (c < bc) { bc = c; best = L; }
+    }
+    if (exact >= need && (!real_half || !(exact & 1))) {
+        double c = length_cost(exact, real_half);
+        if (c <= bc * 1.02) best = exact;
+    }
+    return best;
+}
+
+struct Plan1D {
+    int L = 0;
+    std::vector<int> radices;
+    FftDesc desc{};
+    std::vector<c32> tw;   // all stages, access order
+    std::vector<int> pos;  // pos[k] = LDS position of forward-transform bin k
+};
+
+inline Plan1D make_plan1d(int L) {
+    Plan1D p;
+    p.L = L;
+    p.radices = factorize(L);
+    p.desc.L = L;
+    p.desc.ns = (int)p.radices.size();
+    int n = L;
+    for (int t = 0; t < p.desc.ns; t++) {
+        int R = p.radices[t];
+        int m = n / R;
+        StageDesc& s = p.desc.st[t];
+        s.R = R;
+        s.m = m;
+        if (m > 1) {
+            s.tw_off = (int)p.tw.size();
+            for (int c = 1; c < R; c++)
+                for (int b = 0; b < m; b++) {
+                    double ang = -2.0 * M_PI * (double)((long long)b * c % n) / (double)n;
+                    p.tw.push_back(mk((float)std::cos(ang), (float)std::sin(ang)));
+                }
+        } else {
+            s.tw_off = -1;
+        }
+        n = m;
+    }
+    if (p.tw.empty()) p.tw.push_back(mk(1.f, 0.f));
+    p.pos.resize(L);
+    for (int k = 0; k < L; k++) {
+        int kk = k, pos = 0, len = L;
+        for (int t = 0; t < p.desc.ns; t++) {
+            int R = p.radices[t];
+            len /= R;
+            pos += (kk % R) * len;
+            kk /= R;
+        }
+        p.pos[k] = pos;
+    }
+    return p;
+}
+
+// Pair table for the real <-> half-complex conversion around a complex transform of length M
+// (real length N = 2M).  Entry 0 is the DC/Nyquist item (a = pos(0), b = M: the extra slot);
+// entry p >= 1 pairs bin k = p with bin M-k; if 2k == M the entry is its own partner (a == b).
+inline std::vector<PairEntry> make_pair_table(const Plan1D& pm) {
+    const int M = pm.L;
+    std::vector<PairEntry> t;
+    PairEntry e0;
+    e0.a = pm.pos[0];
+    e0.b = M;
+    e0.w = mk(1.f, 0.f);
+    t.push_back(e0);
+    for (int k = 1; 2 * k <= M; k++) {
+        PairEntry e;
+        e.a = pm.pos[k];
+        e.b = pm.pos[M - k];
+        double ang = -2.0 * M_PI * (double)k / (double)(2 * M);
+        e.w = mk((float)std::cos(ang), (float)std::sin(ang));
+        t.push_back(e);
+    }
+    return t;
+}
+
+// Row pitch (in c32) of one LDS-resident column sequence of M+1 bins: >= M+1 and == 2 mod 16
+// so that the 8 columns of a gather tile land on distinct banks.
+inline int lds_col_pitch(int M) {
+    int p = M + 1;
+    int r = p % 16;
+    p += (r <= 2) ? (2 - r) : (18 - r);
+    return p;
+}
+
+}  // namespace fc

@@ -1,0 +1,91 @@
+// emu.cpp -- TEST-ONLY sequential executor of the engine's workgroup bodies on the host.
+//
+// Compiles the same headers the HIP kernels are built from (kernels_body.hpp, fft_lds.hpp,
+// butterflies.hpp, planner.hpp, pipeline.hpp) with g++ and runs every workgroup one after the
+// other with a single-thread context, so the algorithm (radix butterflies, digit-reversed
+// in-place transforms, pair tables, layouts, argument blocks) can be checked against the oracle
+// in the CPU-only test tier.  It is NOT part of the product: libfftconv.so has no CPU path and
+// never links or loads this file.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "pipeline.hpp"
+
+using namespace fc;
+
+namespace {
+struct HostCtx {
+    int tid = 0, nthreads = 1;
+    void sync() const {}
+};
+}  // namespace
+
+extern "C" {
+
+// Same contract as oracle_conv_fft (and as fftconv_convolution_fft): one group of kernels,
+// sizes may differ per kernel.  Returns 0 on success.
+int emu_conv_fft(const float* data, int H, int W, int F, int max_kh, int max_kw, int n_kernel,
+                 const float* const* kernels, const int* kh, const int* kw, float* const* out,
+                 int* lh_out, int* lw_out) {
+    Geometry g;
+    Tables t;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    if (lh_out) *lh_out = g.Lh;
+    if (lw_out) *lw_out = g.Lw;
+    DeviceTables d;
+    d.tw_m = t.pm.tw.data();
+    d.tw_w = t.pw.tw.data();
+    d.pairs = t.pairs.data();
+    HostCtx ctx;
+    std::vector<c32> lds(FC_LDS_BUDGET / sizeof(c32));
+    std::vector<c32> S(g.spectrum_elems());
+    // garbage-fill to catch reads of never-written cells
+    for (auto& v : S) v = mk(1e30f, -1e30f);
+
+    ColsR2CArgs ia = image_cols_args(g, t, d, data, S.data());
+    for (int plane = 0; plane < F; plane++)
+        for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
+    RowsFwdArgs ra = image_rows_args(g, t, d, S.data());
+    for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
+
+    std::vector<c32> Y(g.y_elems_per_kernel());
+    for (int k = 0; k < n_kernel; k++) {
+        if (kh[k] < 1 || kw[k] < 1 || kh[k] > g.Lh || kw[k] > g.Lw) return -2;
+        if ((kh[k] > max_kh || kw[k] > max_kw) && !g.exact_window) return -3;
+        std::vector<c32> A((size_t)F * g.rows * a_pitch_for(kw[k]));
+        for (auto& v : A) v = mk(1e30f, -1e30f);
+        for (auto& v : Y) v = mk(1e30f, -1e30f);
+        ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
+        for (int plane = 0; plane < F; plane++)
+            for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
+        SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S.data(), Y.data());
+        for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
+        ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
+        for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
+    }
+    return 0;
+}
+
+// 1-D self checks used by tests: forward transform of x (length L) -> natural-order spectrum.
+int emu_fft1d(int L, const float* xin /* 2L floats */, float* xout /* 2L floats */, int inverse) {
+    if (!length_supported(L)) return -1;
+    Plan1D p = make_plan1d(L);
+    HostCtx ctx;
+    std::vector<c32> buf(L);
+    if (!inverse) {
+        for (int i = 0; i < L; i++) buf[i] = mk(xin[2 * i], xin[2 * i + 1]);
+        fft_forward(ctx, buf.data(), L, 1, p.desc, p.tw.data());
+        for (int k = 0; k < L; k++) { xout[2 * k] = buf[p.pos[k]].x; xout[2 * k + 1] = buf[p.pos[k]].y; }
+    } else {
+        for (int k = 0; k < L; k++) buf[p.pos[k]] = mk(xin[2 * k], xin[2 * k + 1]);
+        fft_inverse(ctx, buf.data(), L, 1, p.desc, p.tw.data());
+        for (int i = 0; i < L; i++) { xout[2 * i] = buf[i].x; xout[2 * i + 1] = buf[i].y; }
+    }
+    return 0;
+}
+
+int emu_choose_length(int need, int real_half, int exact) { return choose_length(need, real_half != 0, exact); }
+int emu_length_supported(int L) { return length_supported(L) ? 1 : 0; }
+
+}  // extern "C"
