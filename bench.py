@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the FFT-convolution hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: the image (already
+resident in HBM) is zero-padded and transformed once, then every filter of the batch is
+convolved with it, all maps staying device-resident (SURVEY.md 8(d) "timed region").
+
+Workload at N = 1 (default): BASELINE.json configs[2], the configuration the metric is quoted
+on -- 4096x4096 fp32 image, 256 kernels of 127x127, F = 1 -> 256 maps of 4224x4224.
+N > 1: the filters are sharded over the ranks (one process per GPU): every rank owns
+`--filters` kernels of the same image; rank 0 transforms the image and its spectrum is
+broadcast once over RCCL (torch.distributed "nccl"), the only collective on the path.  Per-GPU
+work is fixed, so "scaling" is "weak"; value is the whole-job rate (all ranks' maps / max time).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
+kernel, algorithmic bytes / live HIP-event time) and `cpu_baseline` (the CPU oracle timed on
+this host on a bounded sample, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIGS = {
+    # name: (H, W, F, kh, kw, filters per GPU, seed)
+    "cfg1": (256, 256, 1, 31, 31, 1, 1),
+    "cfg2": (1024, 1024, 1, 63, 63, 16, 2),
+    "cfg3": (4096, 4096, 1, 127, 127, 256, 3),
+    "cfg4": (4096, 4096, 1, 63, 63, 128, 4),   # 1024 kernels over 8 GPUs
+    "cfg5": (2048, 2048, 1, 63, 63, 64, 5),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def ceil16(n):
+    return (n + 15) // 16 * 16
+
+
+def alg_bytes(H, W, F, kh, kw):
+    """Algorithmic HBM bytes per filter, SURVEY.md 8(d), split by kernel."""
+    fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+    P = fh * fw
+    C = fw * (fh // 2 + 1)
+    spectral = 4 * kh * kw * F + 8 * C * F + 8 * C   # kernel read + image-spectrum read + intermediate write
+    out_cols = 8 * C + 4 * P                          # intermediate read + map write
+    return {"spectral_rows": spectral, "cols_c2r": out_cols, "total": spectral + out_cols, "P": P}
+
+
+def cpu_baseline(cfg, sample_filters):
+    """Times the CPU oracle (port of demoCudaConvolutionFFT.m:78-102, complex128 full transforms)
+    on this host on a bounded sample of the same workload."""
+    import util
+    H, W, F, kh, kw, _, seed = CONFIGS[cfg]
+    orc = util.Oracle()
+    cores = orc.num_threads(0)
+    n = max(1, min(sample_filters, cores))
+    img, ks = util.synth(seed, H, W, F, kh, kw, n)
+    t0 = time.perf_counter()
+    orc.conv_fft(img, kh, kw, ks, threads=0)
+    dt = time.perf_counter() - t0
+    P = ceil16(H + kh - 1) * ceil16(W + kw - 1)
+    return {"value": n * P / dt / 1e9, "unit": "Gpixel-filters/s", "cores": min(cores, n),
+            "kind": "port",
+            "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters), %.1f s wall"
+                      % (cfg, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--filters", type=int, default=0, help="filters per GPU (0 = the config's)")
+    ap.add_argument("--batch-maps", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--check", action="store_true", help="verify a few maps against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import util
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    fc = util.load_package()
+    H, W, F, kh, kw, nf, seed = CONFIGS[args.config]
+    if args.filters > 0:
+        nf = args.filters
+    img_h, _ = util.synth(seed, H, W, F, kh, kw, 0)
+    # kernels: seed 5678+cfg+k with k the GLOBAL filter index (rank-sharded contiguous blocks)
+    import numpy as np
+    kern_h = np.empty((nf, F, kw, kh), dtype=np.float32)  # [n][f][kw][kh] == n MATLAB arrays kh x kw x F
+    for j in range(nf):
+        k = np.random.default_rng(5678 + seed + rank * nf + j).random((kh, kw, F), dtype=np.float32)
+        kern_h[j] = np.transpose(k, (2, 1, 0))
+    img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(img_h, (2, 1, 0)))).to(dev)  # [f][w][h]
+    kern_d = torch.from_numpy(kern_h).to(dev)
+
+    stream = torch.cuda.current_stream(dev)
+    plan = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream)
+    info = plan.info
+    P = info.fft_h * info.fft_w
+    spec = torch.empty(info.spectrum_bytes, dtype=torch.uint8, device=dev)
+    plan.use_spectrum_buffer(spec.data_ptr(), spec.numel())
+    out = torch.empty((nf, info.fft_w, info.fft_h), dtype=torch.float32, device=dev)
+    if args.batch_maps:
+        plan.set_option("batch_maps", args.batch_maps)
+
+    def step():
+        if rank == 0:
+            plan.set_image_device(img_d.data_ptr())
+        if world > 1:
+            dist.broadcast(spec, src=0)
+        plan.mark_spectrum_valid()
+        plan.convolve_packed_device(nf, kern_d.data_ptr(), kh, kw, out.data_ptr())
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel HIP-event timing of the same steps, on the plan's stream (separate pass so the
+    # event records do not sit inside the headline timing)
+    plan.set_option("profile", 1)
+    plan.profile(reset=True)
+    for _ in range(max(1, min(args.steps, 3))):
+        step()
+    torch.cuda.synchronize(dev)
+    prof = plan.profile(reset=True)
+    plan.set_option("profile", 0)
+
+    result = None
+    if rank == 0:
+        ab = alg_bytes(H, W, F, kh, kw)
+        per = {}
+        for name in ("spectral_rows", "cols_c2r"):
+            p = prof[name]
+            if p["launches"]:
+                avg_ms = p["ms"] / p["launches"]
+                units = p["units"] / p["launches"]
+                per[name] = {"avg_ms": avg_ms, "units_per_launch": units,
+                             "gbps": ab[name] * units / (avg_ms * 1e-3) / 1e9}
+        dom = max(per, key=lambda k: prof[k]["ms"]) if per else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if dom and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.config, {}).get(dom)
+            except Exception:
+                traffic = None
+        total_maps = nf * world
+        value = total_maps * P * args.steps / dt / 1e9
+        result = {
+            "metric": "Gpixel-filters/s (padded FFT size)",
+            "value": value,
+            "unit": "Gpixel-filters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %dx%d image (F=%d), %d kernels of %dx%d per GPU -> %d maps of %dx%d, filter-sharded"
+                                   % (args.config, H, W, F, nf, kh, kw, total_maps, info.fft_h, info.fft_w),
+                       "transform": [info.transform_h, info.transform_w],
+                       "filters_per_gpu": nf, "parallelism": "filters x%d + 1 bcast" % world if world > 1 else "single GPU"},
+            "hbm_algorithmic_gbps": ab["total"] * total_maps * args.steps / dt / 1e9,
+            "hbm_frac_of_peak": ab["total"] * total_maps * args.steps / dt / 1e9 / (HBM_PEAK_GBPS * world),
+            "kernels": per,
+            "image_ms": (prof["image_cols"]["ms"] + prof["image_rows"]["ms"]) / max(1, prof["image_cols"]["launches"]),
+        }
+        if dom:
+            result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per[dom]["gbps"], "peak": HBM_PEAK_GBPS,
+                                  "unit": "GB/s", "frac": per[dom]["gbps"] / HBM_PEAK_GBPS, "traffic": traffic,
+                                  "algorithmic_bytes_per_launch": ab[dom] * per[dom]["units_per_launch"],
+                                  "avg_launch_ms": per[dom]["avg_ms"]}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
+        if args.check:
+            orc = util.Oracle()
+            idx = sorted(set([0, nf // 2, nf - 1]))
+            ks = [np.asfortranarray(np.transpose(kern_h[j], (2, 1, 0))) for j in idx]
+            ref = orc.conv_fft(img_h, kh, kw, ks)
+            errs = []
+            for j, r in zip(idx, ref):
+                g = out[j].cpu().numpy().T  # [w][h] -> h x w
+                errs.append(util.rel_err(g, r))
+            result["check_max_rel_err"] = max(errs)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+    plan.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,519 @@
+// fftconv_api.cpp -- host side of libfftconv.so: the C ABI of include/fftconv.h on top of the
+// HIP kernels.  C++ host code in the role of the reference's MEX gateways
+// (src/cudaConvolutionFFT.cu, src/cudaFFTData.cu, src/cudaConvFFTData.cu); no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fftconv.h"
+#include "kernels.hpp"
+#include "pipeline.hpp"
+
+using namespace fc;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(FFTCONV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+enum { PK_KERNEL_COLS = 0, PK_SPECTRAL = 1, PK_OUT_COLS = 2, PK_IMAGE_COLS = 3, PK_IMAGE_ROWS = 4, PK_COUNT = 5 };
+
+struct EventPair {
+    hipEvent_t start, stop;
+    int kind;
+    long units;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FFTCONV_ERR_ALLOC, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+        }
+        cap = n;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t bytes() const { return cap * sizeof(T); }
+};
+
+int cols_threads(const Geometry& g) {
+    long work = (long)g.T_cols * g.M;
+    if (work >= 4096) return 512;
+    if (work >= 1024) return 256;
+    if (work >= 256) return 128;
+    return 64;
+}
+int rows_threads(const Geometry& g) {
+    if (g.Lw >= 2048) return 256;
+    if (g.Lw >= 512) return 128;
+    return 64;
+}
+
+}  // namespace
+
+struct fftconv_plan {
+    Geometry g;
+    Tables t;
+    DeviceTables d;
+    int gpu_id = 0;
+    hipStream_t stream = nullptr;
+    bool have_image = false;
+    DevBuf<c32> tw_m, tw_w;
+    DevBuf<PairEntry> pairs;
+    DevBuf<c32> S;     // image spectrum (own buffer)
+    c32* Sx = nullptr; // caller-owned spectrum buffer, if any
+    c32* spec() const { return Sx ? Sx : S.p; }
+    DevBuf<c32> A;     // kernel column spectra of the current chunk
+    DevBuf<c32> Y;     // intermediate of the current map batch
+    DevBuf<float> K;   // packed kernels staged on the device
+    DevBuf<float> O;   // output staging (pointer-array / host output)
+    DevBuf<float> I;   // image staging (host input)
+    long opt_batch_maps = 0;
+    bool profile = false;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> pool;
+    double prof_ms[PK_COUNT] = {0, 0, 0, 0, 0};
+    long prof_launches[PK_COUNT] = {0, 0, 0, 0, 0};
+    long prof_units[PK_COUNT] = {0, 0, 0, 0, 0};
+
+    size_t cols_lds() const { return (size_t)g.T_cols * g.lds_pitch * sizeof(c32); }
+    size_t rows_lds() const { return (size_t)g.Lw * sizeof(c32) * (g.F > 1 ? 2 : 1); }
+
+    int prof_begin(int kind, long units) {
+        if (!profile) return 0;
+        EventPair ep;
+        if (!pool.empty()) {
+            ep = pool.back();
+            pool.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ep.start));
+            HIP_TRY(hipEventCreate(&ep.stop));
+        }
+        ep.kind = kind;
+        ep.units = units;
+        HIP_TRY(hipEventRecord(ep.start, stream));
+        pending.push_back(ep);
+        return 0;
+    }
+    int prof_end() {
+        if (!profile) return 0;
+        HIP_TRY(hipEventRecord(pending.back().stop, stream));
+        return 0;
+    }
+    int prof_collect() {
+        for (EventPair& ep : pending) {
+            HIP_TRY(hipEventSynchronize(ep.stop));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+            prof_ms[ep.kind] += ms;
+            prof_launches[ep.kind] += 1;
+            prof_units[ep.kind] += ep.units;
+            pool.push_back(ep);
+        }
+        pending.clear();
+        return 0;
+    }
+    void release_all() {
+        for (EventPair& ep : pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+        for (EventPair& ep : pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+        pending.clear();
+        pool.clear();
+        tw_m.release(); tw_w.release(); pairs.release();
+        S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
+    }
+};
+
+namespace {
+
+int use_device(const fftconv_plan* p) {
+    HIP_TRY(hipSetDevice(p->gpu_id));
+    return 0;
+}
+
+// where the maps of a group go
+struct Sink {
+    float* packed = nullptr;        // device base, maps consecutive
+    float* const* ptrs = nullptr;   // or one pointer per map
+    int location = FFTCONV_DEVICE;  // of ptrs
+};
+
+// Core of the per-kernel loop (src/cudaConvolutionFFT.cu:204-291) for n kernels of one size,
+// packed on the device at dk ([n][F][kw][kh]).
+int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
+    const Geometry& g = p->g;
+    if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
+    if (kh < 1 || kw < 1 || kh > g.fft_h || kw > g.fft_w)  // src/cudaConvolutionFFT.cu:242
+        return fail(FFTCONV_ERR_KERNEL_SHAPE,
+                    "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+    if ((kh > g.max_kh || kw > g.max_kw) && !(g.exact_window && kh <= g.Lh && kw <= g.Lw))
+        return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX,
+                    "kernel %dx%d exceeds MAX_KERNEL %dx%d and the internal transform (%dx%d) is not the %dx%d window",
+                    kh, kw, g.max_kh, g.max_kw, g.Lh, g.Lw, g.fft_h, g.fft_w);
+    const size_t per_a = (size_t)g.F * g.rows * a_pitch_for(kw);  // c32 per kernel
+    const size_t a_budget = (size_t)256 << 20;
+    int nbA = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, a_budget / (per_a * sizeof(c32))));
+    const size_t y_bytes = g.y_elems_per_kernel() * sizeof(c32);
+    int nbY = (int)p->opt_batch_maps;
+    if (nbY <= 0) nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)96 << 20) / y_bytes));
+    nbY = std::min(nbY, nbA);
+    if (int rc = p->A.ensure(per_a * nbA)) return rc;
+    if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
+    const bool staged = (sink.packed == nullptr);
+    if (staged)
+        if (int rc = p->O.ensure(g.map_elems() * nbY)) return rc;
+
+    const int T = g.T_cols;
+    const int cthreads = cols_threads(g), rthreads = rows_threads(g);
+    for (int a0 = 0; a0 < n; a0 += nbA) {
+        const int na = std::min(nbA, n - a0);
+        ColsR2CArgs ka = kernel_cols_args(g, p->t, p->d, dk + (size_t)a0 * g.F * kh * kw, kh, kw, p->A.p);
+        if (int rc = p->prof_begin(PK_KERNEL_COLS, na)) return rc;
+        HIP_TRY(launch_cols_r2c(ka, tiles_for(kw, T), na * g.F, cthreads, p->cols_lds(), p->stream));
+        if (int rc = p->prof_end()) return rc;
+        for (int y0 = 0; y0 < na; y0 += nbY) {
+            const int ny = std::min(nbY, na - y0);
+            SpectralRowsArgs sa = spectral_rows_args(g, p->t, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
+            if (int rc = p->prof_begin(PK_SPECTRAL, ny)) return rc;
+            HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
+            if (int rc = p->prof_end()) return rc;
+            float* obase = staged ? p->O.p : sink.packed + (size_t)(a0 + y0) * g.map_elems();
+            ColsC2RArgs ca = cols_c2r_args(g, p->t, p->d, p->Y.p, obase, g.map_elems());
+            if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
+            HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));
+            if (int rc = p->prof_end()) return rc;
+            if (staged) {
+                for (int j = 0; j < ny; j++) {
+                    float* dst = sink.ptrs[a0 + y0 + j];
+                    HIP_TRY(hipMemcpyAsync(dst, p->O.p + (size_t)j * g.map_elems(), g.map_elems() * sizeof(float),
+                                           sink.location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                                           p->stream));
+                }
+                if (sink.location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
+            }
+        }
+    }
+    return 0;
+}
+
+int check_thread_size(const double* thread_size, int n_thread_size) {
+    // src/cudaConvolutionFFT.cu:72-73 -- the optional argument must have 4 elements
+    if (thread_size != nullptr || n_thread_size != 0)
+        if (n_thread_size != 4 || thread_size == nullptr)
+            return fail(FFTCONV_ERR_THREAD_SIZE,
+                        "CUDA Thread Size must be 4 integers : THREAD_PER_BLOCK_H, THREAD_PER_BLOCK_W, "
+                        "THREAD_PER_BLOCK_D, THREAD_PER_BLOCK_2D");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fftconv_fft_size16(int data_size) { return fft_size16(data_size); }
+
+const char* fftconv_last_error(void) { return g_last_error.c_str(); }
+
+const char* fftconv_version(void) { return "fftconv-mi355x 0.1 (gfx950)"; }
+
+int fftconv_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    if (e != hipSuccess || n == 0) return fail(FFTCONV_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature_dim, int max_kernel_h,
+                        int max_kernel_w, int gpu_id, void* hip_stream) {
+    if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    *plan = nullptr;
+    if (data_h < 1 || data_w < 1 || feature_dim < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
+    if (max_kernel_h < 1 || max_kernel_w < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid maximum kernel size");
+    int ndev = 0;
+    if (int rc = fftconv_device_count(&ndev)) return rc;
+    if (gpu_id < 0) HIP_TRY(hipGetDevice(&gpu_id));
+    if (gpu_id >= ndev) return fail(FFTCONV_ERR_NO_DEVICE, "gpu_id %d out of range (%d devices)", gpu_id, ndev);
+    fftconv_plan* p = new (std::nothrow) fftconv_plan();
+    if (!p) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
+    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w)) {
+        delete p;
+        return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
+                    "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform", data_h, data_w,
+                    feature_dim, max_kernel_h, max_kernel_w);
+    }
+    p->gpu_id = gpu_id;
+    p->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    int rc = 0;
+    do {
+        if ((rc = use_device(p))) break;
+        hipError_t e = kernels_init();
+        if (e != hipSuccess) { rc = fail(FFTCONV_ERR_HIP, "kernel setup failed: %s", hipGetErrorString(e)); break; }
+        if ((rc = p->tw_m.ensure(p->t.pm.tw.size()))) break;
+        if ((rc = p->tw_w.ensure(p->t.pw.tw.size()))) break;
+        if ((rc = p->pairs.ensure(p->t.pairs.size()))) break;
+        if ((rc = p->S.ensure(p->g.spectrum_elems()))) break;
+        auto cp = [&](void* dst, const void* src, size_t bytes) -> int {
+            HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+            return 0;
+        };
+        if ((rc = cp(p->tw_m.p, p->t.pm.tw.data(), p->t.pm.tw.size() * sizeof(c32)))) break;
+        if ((rc = cp(p->tw_w.p, p->t.pw.tw.data(), p->t.pw.tw.size() * sizeof(c32)))) break;
+        if ((rc = cp(p->pairs.p, p->t.pairs.data(), p->t.pairs.size() * sizeof(PairEntry)))) break;
+        p->d.tw_m = p->tw_m.p;
+        p->d.tw_w = p->tw_w.p;
+        p->d.pairs = p->pairs.p;
+    } while (0);
+    if (rc) {
+        p->release_all();
+        delete p;
+        return rc;
+    }
+    *plan = p;
+    return 0;
+}
+
+int fftconv_plan_destroy(fftconv_plan* plan) {
+    if (!plan) return 0;
+    (void)hipSetDevice(plan->gpu_id);
+    (void)hipStreamSynchronize(plan->stream);
+    plan->release_all();
+    delete plan;
+    return 0;
+}
+
+int fftconv_plan_get_info(const fftconv_plan* plan, fftconv_plan_info* info) {
+    if (!plan || !info) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    const Geometry& g = plan->g;
+    info->data_h = g.H; info->data_w = g.W; info->feature_dim = g.F;
+    info->max_kernel_h = g.max_kh; info->max_kernel_w = g.max_kw;
+    info->fft_h = g.fft_h; info->fft_w = g.fft_w;
+    info->transform_h = g.Lh; info->transform_w = g.Lw;
+    info->spectrum_rows = g.rows; info->spectrum_pitch = g.s_pitch;
+    info->gpu_id = plan->gpu_id;
+    info->exact_window = g.exact_window ? 1 : 0;
+    info->spectrum_bytes = g.spectrum_elems() * sizeof(c32);
+    info->map_bytes = g.map_elems() * sizeof(float);
+    info->workspace_bytes = plan->A.bytes() + plan->Y.bytes() + plan->K.bytes() + plan->O.bytes() + plan->I.bytes();
+    return 0;
+}
+
+int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) {
+    if (!plan || !data) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
+    if (location != FFTCONV_HOST && location != FFTCONV_DEVICE) return fail(FFTCONV_ERR_INVALID_ARG, "bad location");
+    fftconv_plan* p = plan;
+    const Geometry& g = p->g;
+    if (int rc = use_device(p)) return rc;
+    const float* dimg = data;
+    if (location == FFTCONV_HOST) {
+        const size_t n = (size_t)g.H * g.W * g.F;
+        if (int rc = p->I.ensure(n)) return rc;
+        HIP_TRY(hipMemcpyAsync(p->I.p, data, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
+        dimg = p->I.p;
+    }
+    ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, p->spec());
+    if (int rc = p->prof_begin(PK_IMAGE_COLS, g.F)) return rc;
+    HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
+    if (int rc = p->prof_end()) return rc;
+    RowsFwdArgs ra = image_rows_args(g, p->t, p->d, p->spec());
+    if (int rc = p->prof_begin(PK_IMAGE_ROWS, g.F)) return rc;
+    HIP_TRY(launch_rows_fwd(ra, g.F * g.rows, rows_threads(g), (size_t)g.Lw * sizeof(c32), p->stream));
+    if (int rc = p->prof_end()) return rc;
+    if (location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
+    p->have_image = true;
+    return 0;
+}
+
+int fftconv_plan_spectrum(fftconv_plan* plan, void** device_ptr, size_t* bytes) {
+    if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (device_ptr) *device_ptr = plan->spec();
+    if (bytes) *bytes = plan->g.spectrum_elems() * sizeof(c32);
+    return 0;
+}
+
+int fftconv_plan_use_spectrum_buffer(fftconv_plan* plan, void* device_ptr, size_t bytes) {
+    if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (device_ptr) {
+        if (bytes < plan->g.spectrum_elems() * sizeof(c32) || (reinterpret_cast<uintptr_t>(device_ptr) & 15))
+            return fail(FFTCONV_ERR_INVALID_ARG, "spectrum buffer too small (%zu < %zu bytes) or not 16-byte aligned", bytes,
+                        plan->g.spectrum_elems() * sizeof(c32));
+    }
+    plan->Sx = reinterpret_cast<c32*>(device_ptr);
+    plan->have_image = false;
+    return 0;
+}
+
+int fftconv_plan_mark_spectrum_valid(fftconv_plan* plan) {
+    if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    plan->have_image = true;
+    return 0;
+}
+
+int fftconv_plan_convolve_packed(fftconv_plan* plan, int n_kernel, const float* kernels_device, int kernel_h,
+                                 int kernel_w, float* out_device) {
+    if (!plan || n_kernel < 0) return fail(FFTCONV_ERR_INVALID_ARG, "Wrong number of inputs");
+    if (n_kernel == 0) return 0;
+    if (!kernels_device || !out_device) return fail(FFTCONV_ERR_INVALID_ARG, "NULL kernel or output pointer");
+    if (int rc = use_device(plan)) return rc;
+    Sink sink;
+    sink.packed = out_device;
+    return run_group(plan, n_kernel, kernels_device, kernel_h, kernel_w, sink);
+}
+
+int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* kernels, const int* kernel_h,
+                          const int* kernel_w, int kernel_location, float* const* out, int out_location) {
+    if (!plan || n_kernel < 0) return fail(FFTCONV_ERR_INVALID_ARG, "Wrong number of inputs");
+    if (n_kernel == 0) return 0;
+    if (!kernels || !kernel_h || !kernel_w || !out) return fail(FFTCONV_ERR_INVALID_ARG, "Kernel must be a cell array");
+    fftconv_plan* p = plan;
+    const Geometry& g = p->g;
+    if (int rc = use_device(p)) return rc;
+    if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
+    // validate everything up front so nothing is launched on a bad cell (the reference fails
+    // mid-loop and leaks: SURVEY D3)
+    for (int k = 0; k < n_kernel; k++) {
+        if (!kernels[k] || !out[k]) return fail(FFTCONV_ERR_INVALID_ARG, "kernel or output %d is NULL", k);
+        if (kernel_h[k] < 1 || kernel_w[k] < 1 || kernel_h[k] > g.fft_h || kernel_w[k] > g.fft_w)
+            return fail(FFTCONV_ERR_KERNEL_SHAPE,
+                        "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+    }
+    // groups of consecutive kernels of equal size
+    int k0 = 0;
+    while (k0 < n_kernel) {
+        int k1 = k0 + 1;
+        while (k1 < n_kernel && kernel_h[k1] == kernel_h[k0] && kernel_w[k1] == kernel_w[k0]) k1++;
+        const int n = k1 - k0, kh = kernel_h[k0], kw = kernel_w[k0];
+        const size_t per = (size_t)g.F * kh * kw;
+        if (int rc = p->K.ensure(per * n)) return rc;
+        for (int j = 0; j < n; j++)
+            HIP_TRY(hipMemcpyAsync(p->K.p + per * j, kernels[k0 + j], per * sizeof(float),
+                                   kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                                   p->stream));
+        Sink sink;
+        sink.ptrs = out + k0;
+        sink.location = out_location;
+        if (int rc = run_group(p, n, p->K.p, kh, kw, sink)) return rc;
+        k0 = k1;
+    }
+    if (out_location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int fftconv_plan_synchronize(fftconv_plan* plan) {
+    if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (int rc = use_device(plan)) return rc;
+    HIP_TRY(hipStreamSynchronize(plan->stream));
+    return 0;
+}
+
+int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
+    if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; return 0; }
+    if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int fftconv_plan_get_profile(fftconv_plan* plan, fftconv_profile* prof, int reset) {
+    if (!plan || !prof) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (int rc = use_device(plan)) return rc;
+    if (int rc = plan->prof_collect()) return rc;
+    for (int i = 0; i < PK_COUNT; i++) {
+        prof->ms[i] = plan->prof_ms[i];
+        prof->launches[i] = plan->prof_launches[i];
+        prof->units[i] = plan->prof_units[i];
+        if (reset) { plan->prof_ms[i] = 0; plan->prof_launches[i] = 0; plan->prof_units[i] = 0; }
+    }
+    return 0;
+}
+
+int fftconv_convolution_fft(const float* data, int data_h, int data_w, int feature_dim, int max_kernel_h,
+                            int max_kernel_w, int n_kernel, const float* const* kernels, const int* kernel_h,
+                            const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
+                            int gpu_id, float* const* out, int* fft_h, int* fft_w) {
+    // argument checks in the reference's order (src/cudaConvolutionFFT.cu:45-89)
+    if (!data || data_h < 1 || data_w < 1 || feature_dim < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
+    if (n_kernel < 0 || (n_kernel > 0 && (!kernels || !kernel_h || !kernel_w || !out)))
+        return fail(FFTCONV_ERR_INVALID_ARG, "Kernel must be a cell array");
+    if (int rc = check_thread_size(thread_size, n_thread_size)) return rc;
+    if (kernel_f)
+        for (int k = 0; k < n_kernel; k++)
+            if (kernel_f[k] != feature_dim)  // src/cudaConvolutionFFT.cu:242
+                return fail(FFTCONV_ERR_KERNEL_SHAPE,
+                            "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+    if (fft_h) *fft_h = fft_size16(data_h + max_kernel_h - 1);
+    if (fft_w) *fft_w = fft_size16(data_w + max_kernel_w - 1);
+    fftconv_plan* p = nullptr;
+    if (int rc = fftconv_plan_create(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr)) return rc;
+    int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);
+    if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, FFTCONV_HOST, out, FFTCONV_HOST);
+    std::string keep = g_last_error;
+    fftconv_plan_destroy(p);
+    if (rc) g_last_error = keep;
+    return rc;
+}
+
+int fftconv_fft_data(const float* data, int data_h, int data_w, int feature_dim, int kernel_h, int kernel_w, int gpu_id,
+                     fftconv_plan** fft_data) {
+    if (!fft_data) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid input to MEX file.");
+    *fft_data = nullptr;
+    if (!data) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid input to MEX file.");  // src/cudaFFTData.cu:49-54
+    fftconv_plan* p = nullptr;
+    if (int rc = fftconv_plan_create(&p, data_h, data_w, feature_dim, kernel_h, kernel_w, gpu_id, nullptr)) return rc;
+    if (int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST)) {
+        std::string keep = g_last_error;
+        fftconv_plan_destroy(p);
+        g_last_error = keep;
+        return rc;
+    }
+    *fft_data = p;
+    return 0;
+}
+
+int fftconv_conv_fft_data(fftconv_plan* fft_data, int n_kernel, const float* const* kernels, const int* kernel_h,
+                          const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
+                          float* const* out) {
+    if (!fft_data) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid input to MEX file.");  // src/cudaConvFFTData.cu:68
+    if (int rc = check_thread_size(thread_size, n_thread_size)) return rc;
+    if (kernel_f)
+        for (int k = 0; k < n_kernel; k++)
+            if (kernel_f[k] != fft_data->g.F)
+                return fail(FFTCONV_ERR_KERNEL_SHAPE,
+                            "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+    return fftconv_plan_convolve(fft_data, n_kernel, kernels, kernel_h, kernel_w, FFTCONV_HOST, out, FFTCONV_HOST);
+}
+
+}  // extern "C"

@@ -1,0 +1,17 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_body.hpp"
+
+namespace fc {
+
+// Raises the dynamic-LDS limit of every kernel to the full 160 KiB of a gfx950 CU.
+hipError_t kernels_init();
+
+hipError_t launch_cols_r2c(const ColsR2CArgs& a, int tiles, int planes, int threads, size_t lds_bytes, hipStream_t s);
+hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t lds_bytes, hipStream_t s);
+hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);
+hipError_t launch_cols_c2r(const ColsC2RArgs& a, int tiles, int kernels, int threads, size_t lds_bytes, hipStream_t s);
+
+}  // namespace fc

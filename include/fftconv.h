@@ -1,0 +1,188 @@
+/*
+ * fftconv.h -- C ABI of the MI355X-native 2-D FFT-convolution engine (libfftconv.so).
+ *
+ * This is the drop-in boundary for the reference's `cudaConvolutionFFT` hot path
+ * (chrischoy/CUDA-FFT-Convolution).  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree).  Plain C: pointers and sizes only, no
+ * torch / HIP types in the signatures (a HIP stream is passed as an opaque void*).
+ *
+ * Conventions shared by all entry points
+ *   - Arrays use MATLAB column-major layout exactly as the reference reads them:
+ *     data is H x W x F, element (y, x, z) at z*H*W + x*H + y
+ *     (src/cudaConvFFTData.cuh:26-27); kernel k is kh x kw x F in the same layout.
+ *   - Every result map is the FULL padded window FFT_H x FFT_W (column-major, NOT cropped),
+ *     FFT_X = fftconv_fft_size16(DATA_X + MAX_KERNEL_X - 1)
+ *     (src/cudaConvolutionFFT.cu:103-110,198-200).  Cells outside the linear-convolution
+ *     support (DATA+k-1) are zero up to fp32 round-off, as in the reference.
+ *   - The product is a plain complex multiply (convolution, not correlation:
+ *     src/cudaConvFFTData.cuh:62-65); flip the kernel for template matching
+ *     (demoCudaConvolutionFFT.m:63-69).
+ *   - Functions return FFTCONV_OK (0) or a negative fftconv_status; the message of the last
+ *     failure on the calling thread is returned by fftconv_last_error().  The library never
+ *     calls exit() (the reference's CUDA_SAFE_CALL does: src/cudaConvFFTData.h:6-29) and
+ *     releases all device memory on error paths.
+ *   - There is no CPU fallback: without a usable HIP device every compute entry point fails
+ *     with FFTCONV_ERR_NO_DEVICE / FFTCONV_ERR_HIP.
+ */
+#ifndef FFTCONV_H
+#define FFTCONV_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fftconv_status {
+    FFTCONV_OK = 0,
+    FFTCONV_ERR_INVALID_ARG = -1,      /* "Wrong number of inputs" / "Invalid data input" class (src/cudaConvolutionFFT.cu:45-54) */
+    FFTCONV_ERR_THREAD_SIZE = -2,      /* thread-size array does not have 4 elements (src/cudaConvolutionFFT.cu:72-73) */
+    FFTCONV_ERR_KERNEL_SHAPE = -3,     /* feature mismatch or kernel larger than the FFT window (src/cudaConvolutionFFT.cu:242-243) */
+    FFTCONV_ERR_KERNEL_EXCEEDS_MAX = -4, /* kernel larger than MAX_KERNEL and the internal transform is not the ceil16 window */
+    FFTCONV_ERR_UNSUPPORTED_SIZE = -5, /* transform does not fit the single-pass LDS engine */
+    FFTCONV_ERR_NO_DEVICE = -6,
+    FFTCONV_ERR_HIP = -7,              /* a HIP runtime call failed; message has the HIP error string */
+    FFTCONV_ERR_ALLOC = -8,
+    FFTCONV_ERR_NO_IMAGE = -9          /* convolve called before an image spectrum exists */
+} fftconv_status;
+
+/* Error id the MEX gateway raises for argument errors (src/cudaConvolutionFFT.cu:30). */
+#define FFTCONV_MEX_ERROR_ID "cudaConvFFTData:InvalidInput"
+
+enum { FFTCONV_HOST = 0, FFTCONV_DEVICE = 1 };
+
+/* computeFFTsize16 (src/cudaConvFFTData.h:96-102): round up to a multiple of 16. */
+int fftconv_fft_size16(int data_size);
+
+/* Message of the last failure on this thread ("" if none). */
+const char *fftconv_last_error(void);
+
+/* Library version string. */
+const char *fftconv_version(void);
+
+/* Number of visible HIP devices (0 and FFTCONV_ERR_NO_DEVICE when there is none). */
+int fftconv_device_count(int *count);
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot entry: the body of mexFunction in src/cudaConvolutionFFT.cu:27-311.
+ *
+ *   cvcell = cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell[, threadSize][, gpuId])
+ *
+ *   data, data_h, data_w, feature_dim   prhs[0]  host single H x W x F (:49-54,92-99); F = 1 is
+ *                                                accepted (the reference rejects it)
+ *   max_kernel_h, max_kernel_w          prhs[1], prhs[2] (:58-59)
+ *   n_kernel, kernels, kernel_h/_w      prhs[3]  cell array of host single kh x kw x F (:64-67,207-222)
+ *   kernel_f                            per-kernel feature count for the :242 check; NULL = F
+ *   thread_size, n_thread_size          prhs[4]  optional; must have 4 elements (:72-73); the
+ *                                                values are accepted and ignored (block shapes
+ *                                                are the engine's business)
+ *   gpu_id                              prhs[5]  0-based device (:85-89); < 0 = current device
+ *   out                                 plhs[0]  n_kernel caller buffers of FFT_H*FFT_W floats
+ *                                                (the reference allocates them: :284-288)
+ *   fft_h, fft_w                        out, nullable: the window size
+ * Synchronous: results are complete on return, all device memory is released.
+ * ------------------------------------------------------------------------------------------ */
+int fftconv_convolution_fft(const float *data, int data_h, int data_w, int feature_dim,
+                            int max_kernel_h, int max_kernel_w,
+                            int n_kernel, const float *const *kernels,
+                            const int *kernel_h, const int *kernel_w, const int *kernel_f,
+                            const double *thread_size, int n_thread_size,
+                            int gpu_id,
+                            float *const *out, int *fft_h, int *fft_w);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan API: the state the reference keeps inside one mexFunction call (cuFFT plans
+ * src/cudaConvolutionFFT.cu:122-142, image spectrum d_CFFT_DATA :165-168, scratch :182-185)
+ * and, in its multi-GPU sketch, inside a ConvPlan (src/cudaConvFFTDataStreams.cu:273-328),
+ * made a first-class object so the image spectrum is computed once and reused against any
+ * number of kernels and calls (what cudaFFTData / cudaConvFFTData exist for:
+ * src/cudaFFTData.cu:18-160, src/cudaConvFFTData.cu:24-306).
+ * A plan is bound to one device; calls on one plan must not overlap.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fftconv_plan fftconv_plan;
+
+typedef struct fftconv_plan_info {
+    int data_h, data_w, feature_dim;
+    int max_kernel_h, max_kernel_w;
+    int fft_h, fft_w;          /* output window (reference's ceil16 sizes) */
+    int transform_h, transform_w; /* internal transform lengths (>= DATA + MAXK - 1) */
+    int spectrum_rows;         /* transform_h / 2 + 1 */
+    int spectrum_pitch;        /* complex elements per spectrum row */
+    int gpu_id;
+    int exact_window;          /* 1 if transform == window: circular modulus equals the reference's */
+    size_t spectrum_bytes;     /* size of the image spectrum buffer */
+    size_t map_bytes;          /* fft_h * fft_w * sizeof(float) */
+    size_t workspace_bytes;    /* device scratch currently held */
+} fftconv_plan_info;
+
+/* hip_stream: hipStream_t to run on (NULL = the device's default stream). */
+int fftconv_plan_create(fftconv_plan **plan, int data_h, int data_w, int feature_dim,
+                        int max_kernel_h, int max_kernel_w, int gpu_id, void *hip_stream);
+int fftconv_plan_destroy(fftconv_plan *plan);
+int fftconv_plan_get_info(const fftconv_plan *plan, fftconv_plan_info *info);
+
+/* Zero-pad + forward transform of the image: padData + cufftExecR2C on the data
+ * (src/cudaConvolutionFFT.cu:144-169; src/cudaFFTData.cu:105-147).
+ * location: FFTCONV_HOST (pageable or pinned host memory) or FFTCONV_DEVICE. Asynchronous on the
+ * plan's stream for device input. */
+int fftconv_plan_set_image(fftconv_plan *plan, const float *data, int location);
+
+/* Device pointer + size of the image spectrum (library-owned, valid until destroy).  This is the
+ * buffer the multi-GPU path broadcasts (the reference's cudaMemcpyPeerAsync of d_CFFT_DATA,
+ * src/cudaConvFFTDataStreams.cu:279-289): rank 0 fills it with set_image, the others receive it
+ * and call fftconv_plan_mark_spectrum_valid.  The layout is internal. */
+int fftconv_plan_spectrum(fftconv_plan *plan, void **device_ptr, size_t *bytes);
+int fftconv_plan_mark_spectrum_valid(fftconv_plan *plan);
+/* Make the plan keep its image spectrum in caller-owned device memory (>= spectrum_bytes, 16-byte
+ * aligned, must outlive the plan or the next call of this function; NULL = back to the plan's own
+ * buffer).  Lets a communication library that owns its buffers (torch.distributed / RCCL)
+ * broadcast the spectrum with no staging copy.  Invalidates the current spectrum. */
+int fftconv_plan_use_spectrum_buffer(fftconv_plan *plan, void *device_ptr, size_t bytes);
+
+/* Per-kernel loop of src/cudaConvolutionFFT.cu:204-291 for arbitrary (possibly different)
+ * kernel sizes.  kernels[k]: kh[k] x kw[k] x F, host or device (gpuArray kernels: :224-238);
+ * out[k]: FFT_H*FFT_W floats, host or device.  Synchronous for host output. */
+int fftconv_plan_convolve(fftconv_plan *plan, int n_kernel,
+                          const float *const *kernels, const int *kernel_h, const int *kernel_w,
+                          int kernel_location,
+                          float *const *out, int out_location);
+
+/* Same for n_kernel equally-sized kernels packed contiguously in device memory
+ * ([n][F][kw][kh], i.e. n consecutive MATLAB arrays) writing n consecutive maps to device
+ * memory ([n][FFT_W][FFT_H]).  Fully asynchronous on the plan's stream: this is the
+ * device-resident mode the benchmark times. */
+int fftconv_plan_convolve_packed(fftconv_plan *plan, int n_kernel, const float *kernels_device,
+                                 int kernel_h, int kernel_w, float *out_device);
+
+/* Block until everything queued on the plan's stream has finished. */
+int fftconv_plan_synchronize(fftconv_plan *plan);
+
+/* Options: "batch_maps" (kernels per spectral/output launch, 0 = auto),
+ *          "profile" (1: time every kernel launch with HIP events on the plan's stream). */
+int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
+
+typedef struct fftconv_profile {
+    /* accumulated since the last reset; index 0 kernel_cols (h forward of the kernels),
+     * 1 spectral_rows, 2 cols_c2r (output), 3 image_cols, 4 image_rows */
+    double ms[5];
+    long launches[5];
+    long units[5];  /* kernels (maps) processed by those launches */
+} fftconv_profile;
+int fftconv_plan_get_profile(fftconv_plan *plan, fftconv_profile *prof, int reset);
+
+/* ------------------------------------------------------------------------------------------
+ * Two-step API of the reference, as thin aliases of the plan API:
+ *   fftData = cudaFFTData(data, kernelH, kernelW)        src/cudaFFTData.cu:18-160
+ *   cvcell  = cudaConvFFTData(fftData, kernelCell[, threadSize])  src/cudaConvFFTData.cu:24-306
+ * The handle plays the role of the complex gpuArray the reference returns.
+ * ------------------------------------------------------------------------------------------ */
+int fftconv_fft_data(const float *data, int data_h, int data_w, int feature_dim,
+                     int kernel_h, int kernel_w, int gpu_id, fftconv_plan **fft_data);
+int fftconv_conv_fft_data(fftconv_plan *fft_data, int n_kernel, const float *const *kernels,
+                          const int *kernel_h, const int *kernel_w, const int *kernel_f,
+                          const double *thread_size, int n_thread_size, float *const *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFTCONV_H */
