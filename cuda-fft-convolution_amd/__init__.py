@@ -71,6 +71,26 @@ EXPORTED_SYMBOLS = (
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's); if libfftconv.so pulled in the system copy first, a later
+    `import torch` would bring a second runtime into the process and see no GPUs, and streams or
+    events could not be shared.  So when torch is installed, its copy is loaded first (by path,
+    without importing torch) and libfftconv.so binds to it through the SONAME."""
+    if os.environ.get("FFTCONV_NO_TORCH_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """Loads libfftconv.so (built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``).
     Fails loudly when it is missing: there is no fallback implementation."""
@@ -80,6 +100,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise FFTConvError(-7, "HIP extension %s is missing; build it with `make -C %s`"
                            % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    _preload_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     pi = ctypes.POINTER(ctypes.c_int)

@@ -79,7 +79,7 @@ inline double length_cost(int L, bool real_half) {
 }
 
 // Cheapest supported length >= need (even if real_half).  `exact` (>= need, e.g. the ceil16
-// window) wins ties and is preferred when within 2 % of the optimum, so that the common case
+// window) wins ties and is preferred when within 10 % of the optimum, so that the common case
 // reproduces the reference's circular-convolution modulus exactly.
 inline int choose_length(int need, bool real_half, int exact) {
     if (need < 1) need = 1;
@@ -93,7 +93,7 @@ inline int choose_length(int need, bool real_half, int exact) {
     }
     if (exact >= need && (!real_half || !(exact & 1))) {
         double c = length_cost(exact, real_half);
-        if (c <= bc * 1.02) best = exact;
+        if (c <= bc * 1.10) best = exact;
     }
     return best;
 }

@@ -23,8 +23,69 @@ struct HostCtx {
 
 extern "C" {
 
-// Same contract as oracle_conv_fft (and as fftconv_convolution_fft): one group of kernels,
-// sizes may differ per kernel.  Returns 0 on success.
+// Size (in complex elements) of the image spectrum buffer of a plan.
+long emu_spectrum_elems(int H, int W, int F, int max_kh, int max_kw) {
+    Geometry g;
+    Tables t;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    return (long)g.spectrum_elems();
+}
+
+// Image spectrum (what fftconv_plan_set_image leaves in the plan's spectrum buffer).
+int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int max_kw, float* spec_out) {
+    Geometry g;
+    Tables t;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    DeviceTables d;
+    d.tw_m = t.pm.tw.data();
+    d.tw_w = t.pw.tw.data();
+    d.pairs = t.pairs.data();
+    HostCtx ctx;
+    std::vector<c32> lds(FC_LDS_BUDGET / sizeof(c32));
+    c32* S = reinterpret_cast<c32*>(spec_out);
+    // garbage-fill to catch reads of never-written cells
+    for (size_t i = 0; i < g.spectrum_elems(); i++) S[i] = mk(1e30f, -1e30f);
+    ColsR2CArgs ia = image_cols_args(g, t, d, data, S);
+    for (int plane = 0; plane < F; plane++)
+        for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
+    RowsFwdArgs ra = image_rows_args(g, t, d, S);
+    for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
+    return 0;
+}
+
+// Per-kernel loop from a given spectrum (what fftconv_plan_convolve does).
+int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, int max_kw, int n_kernel,
+                          const float* const* kernels, const int* kh, const int* kw, float* const* out) {
+    Geometry g;
+    Tables t;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    DeviceTables d;
+    d.tw_m = t.pm.tw.data();
+    d.tw_w = t.pw.tw.data();
+    d.pairs = t.pairs.data();
+    HostCtx ctx;
+    std::vector<c32> lds(FC_LDS_BUDGET / sizeof(c32));
+    const c32* S = reinterpret_cast<const c32*>(spec);
+    std::vector<c32> Y(g.y_elems_per_kernel());
+    for (int k = 0; k < n_kernel; k++) {
+        if (kh[k] < 1 || kw[k] < 1 || kh[k] > g.fft_h || kw[k] > g.fft_w) return -2;
+        if ((kh[k] > max_kh || kw[k] > max_kw) && !(g.exact_window && kh[k] <= g.Lh && kw[k] <= g.Lw)) return -3;
+        std::vector<c32> A((size_t)F * g.rows * a_pitch_for(kw[k]));
+        for (auto& v : A) v = mk(1e30f, -1e30f);
+        for (auto& v : Y) v = mk(1e30f, -1e30f);
+        ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
+        for (int plane = 0; plane < F; plane++)
+            for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
+        SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
+        for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
+        ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
+        for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
+    }
+    return 0;
+}
+
+// Same contract as oracle_conv_fft (and as fftconv_convolution_fft): sizes may differ per
+// kernel.  Returns 0 on success.
 int emu_conv_fft(const float* data, int H, int W, int F, int max_kh, int max_kw, int n_kernel,
                  const float* const* kernels, const int* kh, const int* kw, float* const* out,
                  int* lh_out, int* lw_out) {
@@ -33,38 +94,9 @@ int emu_conv_fft(const float* data, int H, int W, int F, int max_kh, int max_kw,
     if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
     if (lh_out) *lh_out = g.Lh;
     if (lw_out) *lw_out = g.Lw;
-    DeviceTables d;
-    d.tw_m = t.pm.tw.data();
-    d.tw_w = t.pw.tw.data();
-    d.pairs = t.pairs.data();
-    HostCtx ctx;
-    std::vector<c32> lds(FC_LDS_BUDGET / sizeof(c32));
-    std::vector<c32> S(g.spectrum_elems());
-    // garbage-fill to catch reads of never-written cells
-    for (auto& v : S) v = mk(1e30f, -1e30f);
-
-    ColsR2CArgs ia = image_cols_args(g, t, d, data, S.data());
-    for (int plane = 0; plane < F; plane++)
-        for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
-    RowsFwdArgs ra = image_rows_args(g, t, d, S.data());
-    for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
-
-    std::vector<c32> Y(g.y_elems_per_kernel());
-    for (int k = 0; k < n_kernel; k++) {
-        if (kh[k] < 1 || kw[k] < 1 || kh[k] > g.Lh || kw[k] > g.Lw) return -2;
-        if ((kh[k] > max_kh || kw[k] > max_kw) && !g.exact_window) return -3;
-        std::vector<c32> A((size_t)F * g.rows * a_pitch_for(kw[k]));
-        for (auto& v : A) v = mk(1e30f, -1e30f);
-        for (auto& v : Y) v = mk(1e30f, -1e30f);
-        ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
-        for (int plane = 0; plane < F; plane++)
-            for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
-        SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S.data(), Y.data());
-        for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
-        ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
-        for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
-    }
-    return 0;
+    std::vector<float> spec(2 * g.spectrum_elems());
+    if (int rc = emu_image_spectrum(data, H, W, F, max_kh, max_kw, spec.data())) return rc;
+    return emu_convolve_spectrum(spec.data(), H, W, F, max_kh, max_kw, n_kernel, kernels, kh, kw, out);
 }
 
 // 1-D self checks used by tests: forward transform of x (length L) -> natural-order spectrum.

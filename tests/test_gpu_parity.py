@@ -1,0 +1,260 @@
+"""GPU tier (-m gpu): parity of the HIP path, called through the C ABI (ctypes), against the CPU
+oracle and the committed golden fixtures; edge cases and error behaviour of the reference's
+interface; size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: max|out - ref| / max|ref| <= 1e-4 per map (north_star: "within 1e-4 relative fp32");
+the fp32 engine is in practice ~1e-6, so the small cases assert 1e-5 to catch regressions."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import golden_util
+import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+TIGHT = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fc(fftconv):
+    assert fftconv.device_count() >= 1, "GPU tests need a GPU (no CPU fallback exists)"
+    return fftconv
+
+
+@pytest.mark.parametrize("case", golden_util.golden_cases())
+def test_golden_fixtures(fc, case):
+    data, mkh, mkw, kernels, expect = golden_util.load_case(case)
+    got = fc.cudaConvolutionFFT(data, mkh, mkw, kernels)
+    assert len(got) == len(expect)
+    for g, e in zip(got, expect):
+        assert g.shape == e.shape and g.dtype == np.float32 and g.flags.f_contiguous
+        assert util.rel_err(g, e) < TIGHT
+
+
+SHAPES = [
+    (64, 8, 5, 10, 4, 3),      # the reference's demo problem (demoCudaConvolutionFFT.m:37-42)
+    (33, 47, 3, 7, 5, 2), (100, 90, 2, 13, 17, 2), (256, 256, 1, 31, 31, 1),   # cfg1
+    (1, 1, 1, 1, 1, 1), (2, 3, 1, 1, 2, 1), (5, 5, 2, 5, 5, 1), (17, 1, 1, 3, 1, 1), (1, 40, 2, 1, 9, 2),
+    (300, 20, 1, 21, 3, 1), (130, 260, 3, 12, 8, 2), (50, 60, 1, 19, 23, 1), (31, 31, 7, 31, 31, 2),
+    (500, 333, 2, 40, 27, 3), (1000, 77, 1, 88, 5, 2), (77, 1000, 1, 5, 88, 2), (513, 511, 1, 2, 2, 2),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_parity_vs_oracle(fc, oracle, shape):
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape))
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(n)]
+    if n > 1:
+        ks[1] = rng.random((max(1, kh - 2), max(1, kw - 1), F), dtype=np.float32)   # ragged cell
+    got = fc.cudaConvolutionFFT(data, kh, kw, ks, [8, 8, 8, 16], 0)
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    for g, r in zip(got, ref):
+        assert g.shape == (util.ceil16(H + kh - 1), util.ceil16(W + kw - 1))
+        assert util.rel_err(g, r) < TIGHT
+
+
+def test_signed_data_and_large_dynamic_range(fc, oracle):
+    rng = np.random.default_rng(9)
+    data = (rng.standard_normal((200, 150, 2)) * 1e3).astype(np.float32)
+    ks = [(rng.standard_normal((9, 11, 2)) * 1e-3).astype(np.float32)]
+    got = fc.cudaConvolutionFFT(data, 9, 11, ks)
+    assert util.rel_err(got[0], oracle.conv_fft(data, 9, 11, ks)[0]) < TIGHT
+
+
+def test_demo_invariants(fc):
+    """demoCudaConvolutionFFT.m:110-113: same kernel twice -> identical maps; kernel2(1) = 100
+    -> difference is the scaled first data channel at the top-left."""
+    data, cn, cm, ks, _ = golden_util.load_case("case_demo")
+    n, m, _ = data.shape
+    got = fc.cudaConvolutionFFT(data, cn, cm, ks, [8, 8, 8, 16], 0)
+    assert np.array_equal(got[0], got[2])
+    diff = got[1].astype(np.float64) - got[0]
+    want = np.zeros_like(diff)
+    want[:n, :m] = (100.0 - float(ks[0][0, 0, 0])) * data[:, :, 0]
+    assert np.abs(diff - want).max() / np.abs(want).max() < TOL
+    assert np.abs(got[0][n + cn - 1:, :]).max() < TOL * np.abs(got[0]).max()
+
+
+def test_empty_cell(fc):
+    assert fc.cudaConvolutionFFT(np.zeros((8, 8, 1), np.float32), 3, 3, []) == []
+
+
+def test_2d_inputs_are_single_channel(fc, oracle):
+    # the reference rejects H x W x 1; the engine accepts it
+    rng = np.random.default_rng(1)
+    data = rng.random((40, 30), dtype=np.float32)
+    k = rng.random((5, 7), dtype=np.float32)
+    got = fc.cudaConvolutionFFT(data, 5, 7, [k])
+    assert util.rel_err(got[0], oracle.conv_fft(data, 5, 7, [k])[0]) < TIGHT
+
+
+def test_oversize_kernel_wraps_like_the_reference_when_window_is_exact(fc, oracle):
+    data, mkh, mkw, kernels, expect = golden_util.load_case("case_wrap")
+    got = fc.cudaConvolutionFFT(data, mkh, mkw, kernels)
+    assert util.rel_err(got[0], expect[0]) < TIGHT
+    assert util.rel_err(got[0], oracle.conv_direct(data, mkh, mkw, kernels[0])) < TIGHT
+
+
+def test_error_behaviour(fc):
+    data = np.zeros((64, 8, 2), np.float32)
+    k = np.zeros((10, 4, 2), np.float32)
+    with pytest.raises(fc.FFTConvError) as e:    # kernel larger than the FFT window, :242
+        fc.cudaConvolutionFFT(data, 10, 4, [np.zeros((81, 4, 2), np.float32)])
+    assert e.value.status == -3
+    with pytest.raises(fc.FFTConvError) as e:    # > MAXK and transform (80x11) != window (80x16)
+        fc.cudaConvolutionFFT(data, 10, 4, [np.zeros((10, 6, 2), np.float32)])
+    assert e.value.status == -4
+    with pytest.raises(fc.FFTConvError) as e:    # bad gpu id
+        fc.cudaConvolutionFFT(data, 10, 4, [k], None, 99)
+    assert e.value.status == -6
+    # a failure leaves the library usable
+    assert len(fc.cudaConvolutionFFT(data, 10, 4, [k])) == 1
+
+
+def test_two_step_api_and_plan_reuse(fc, oracle):
+    """cudaFFTData + cudaConvFFTData (src/cudaFFTData.cu, src/cudaConvFFTData.cu): one image
+    spectrum reused across calls; a second image through the same plan"""
+    rng = np.random.default_rng(4)
+    data = rng.random((90, 70, 3), dtype=np.float32)
+    ks = [rng.random((11, 9, 3), dtype=np.float32) for _ in range(5)]
+    h = fc.cudaFFTData(data, 11, 9)
+    a = fc.cudaConvFFTData(h, ks[:2])
+    b = fc.cudaConvFFTData(h, ks[2:], [16, 8, 8, 32])
+    ref = oracle.conv_fft(data, 11, 9, ks)
+    for g, r in zip(a + b, ref):
+        assert util.rel_err(g, r) < TIGHT
+    with pytest.raises(fc.FFTConvError):
+        fc.cudaConvFFTData(h, ks[:1], [1, 2, 3])
+    data2 = rng.random((90, 70, 3), dtype=np.float32)
+    h.set_image(data2)
+    assert util.rel_err(h.convolve(ks[:1])[0], oracle.conv_fft(data2, 11, 9, ks[:1])[0]) < TIGHT
+    h.destroy()
+
+
+def test_convolve_before_image_fails(fc):
+    with fc.Plan(16, 16, 1, 3, 3) as p:
+        with pytest.raises(fc.FFTConvError) as e:
+            p.convolve([np.zeros((3, 3, 1), np.float32)])
+        assert e.value.status == -9
+
+
+def test_device_resident_packed_path(fc, oracle):
+    """the mode the benchmark times: image, kernels and maps all in HBM (torch tensors as plumbing)"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H, W, F, kh, kw, n = 300, 260, 2, 15, 13, 7
+    img, ks = util.synth(21, H, W, F, kh, kw, n)
+    img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (2, 1, 0)))).to(dev)
+    kpk = np.stack([np.transpose(k, (2, 1, 0)) for k in ks])
+    k_d = torch.from_numpy(np.ascontiguousarray(kpk)).to(dev)
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        with fc.Plan(H, W, F, kh, kw, 0, s.cuda_stream) as p:
+            out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+            for batch in (0, 1, 3):
+                p.set_option("batch_maps", batch)
+                out.fill_(float("nan"))
+                p.set_image_device(img_d.data_ptr())
+                p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+                p.synchronize()
+                ref = oracle.conv_fft(img, kh, kw, ks)
+                got = out.cpu().numpy()
+                for j in range(n):
+                    assert util.rel_err(got[j].T, ref[j]) < TIGHT
+
+
+def test_external_spectrum_buffer_roundtrip(fc, oracle):
+    """the multi-GPU hand-off: spectrum produced into caller memory by one plan, consumed by another"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H, W, F, kh, kw = 120, 100, 1, 9, 9
+    img, ks = util.synth(31, H, W, F, kh, kw, 2)
+    with fc.Plan(H, W, F, kh, kw) as src, fc.Plan(H, W, F, kh, kw) as dst:
+        buf = torch.empty(src.info.spectrum_bytes, dtype=torch.uint8, device=dev)
+        src.use_spectrum_buffer(buf.data_ptr(), buf.numel())
+        src.set_image(img)
+        src.synchronize()
+        buf2 = buf.clone()                       # stands in for the broadcast
+        dst.use_spectrum_buffer(buf2.data_ptr(), buf2.numel())
+        with pytest.raises(fc.FFTConvError):
+            dst.convolve(ks)                     # not marked valid yet
+        dst.mark_spectrum_valid()
+        got = dst.convolve(ks)
+        for g, r in zip(got, oracle.conv_fft(img, kh, kw, ks)):
+            assert util.rel_err(g, r) < TIGHT
+        with pytest.raises(fc.FFTConvError):
+            dst.use_spectrum_buffer(buf2.data_ptr(), 16)
+
+
+# ---------------------------------------------------------------- BASELINE.json full sizes
+
+def _device_run(fc, torch, img, ks_packed, kh, kw):
+    dev = torch.device("cuda", 0)
+    F, W, H = img.shape
+    n = ks_packed.shape[0]
+    with fc.Plan(H, W, F, kh, kw) as p:
+        out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+        p.set_image_device(img.data_ptr())
+        p.convolve_packed_device(n, ks_packed.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+    return out
+
+
+def test_cfg2_full_size_vs_oracle(fc, oracle):
+    """BASELINE configs[1]: 1024x1024 image, 16 kernels of 63x63 -> 16 maps of 1088x1088"""
+    img, ks = util.synth(2, 1024, 1024, 1, 63, 63, 16)
+    got = fc.cudaConvolutionFFT(img, 63, 63, ks)
+    ref = oracle.conv_fft(img, 63, 63, ks)
+    for g, r in zip(got, ref):
+        assert util.rel_err(g, r) < TOL
+
+
+def test_cfg3_full_size_properties(fc, oracle):
+    """BASELINE configs[2] geometry (4096x4096 image, 127x127 kernels, 4224x4224 maps), checked
+    through size-independent properties plus one map against the oracle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H = W = 4096
+    kh = kw = 127
+    g = torch.Generator(device="cpu").manual_seed(1234 + 3)
+    img = torch.rand((1, W, H), generator=g, dtype=torch.float32)
+    ks = torch.rand((4, 1, kw, kh), generator=g, dtype=torch.float32)
+    ks[1].zero_(); ks[1, 0, 5, 9] = 1.0          # delta at (h=9, w=5)
+    ks[3] = 2.0 * ks[0] - 3.0 * ks[2]            # linear combination
+    out = _device_run(fc, torch, img.to(dev), ks.to(dev), kh, kw)
+    fw, fh = out.shape[1], out.shape[2]
+    assert (fh, fw) == (4224, 4224)
+    o = out.double()
+    scale = float(o[0].abs().max())
+    # delta kernel -> the image shifted by (9, 5), zero elsewhere
+    want = torch.zeros((fw, fh), dtype=torch.float64, device=dev)
+    want[5:5 + W, 9:9 + H] = img[0].to(dev).double()
+    assert float((o[1] - want).abs().max()) < TOL
+    # linearity
+    assert float((o[3] - (2.0 * o[0] - 3.0 * o[2])).abs().max()) / scale < TOL
+    # checksum: sum(map) = sum(image) * sum(kernel)
+    for j in (0, 2):
+        s_map = float(o[j].sum())
+        s_ref = float(img.double().sum()) * float(ks[j].double().sum())
+        assert abs(s_map - s_ref) / abs(s_ref) < 1e-5
+    # outside the linear support (4222 x 4222) the window is ~0
+    assert float(o[0][4222:, :].abs().max()) / scale < TOL and float(o[0][:, 4222:].abs().max()) / scale < TOL
+    # one full map against the oracle
+    img_np = np.asfortranarray(np.transpose(img.numpy(), (2, 1, 0)))
+    k_np = np.asfortranarray(np.transpose(ks[0].numpy(), (2, 1, 0)))
+    ref = oracle.conv_fft(img_np, kh, kw, [k_np])[0]
+    assert util.rel_err(out[0].cpu().numpy().T, ref) < TOL
+
+
+def test_cfg4_and_cfg5_geometry_vs_oracle(fc, oracle):
+    """BASELINE configs[3] (4160x4160 maps, 63x63 kernels) and configs[4] (2048x2048 image ->
+    2112x2112): one map each against the oracle."""
+    for seed, (H, W, kh, kw) in {4: (4096, 4096, 63, 63), 5: (2048, 2048, 63, 63)}.items():
+        img, ks = util.synth(seed, H, W, 1, kh, kw, 1)
+        got = fc.cudaConvolutionFFT(img, kh, kw, ks)
+        ref = oracle.conv_fft(img, kh, kw, ks)
+        assert util.rel_err(got[0], ref[0]) < TOL

@@ -1,0 +1,170 @@
+"""CPU tier: host logic of the product (planner, tables, layouts, argument blocks) exercised
+through the test-only emulator, and the C-ABI library's load/export/no-GPU behaviour."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util
+import util
+
+EMU_DIR = os.path.join(util.ROOT, "tests", "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(EMU_DIR, "libfftconv_emu.so")
+    subprocess.run(["make", "-C", EMU_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    lib = ctypes.CDLL(so)
+    lib.emu_spectrum_elems.restype = ctypes.c_long
+    return lib
+
+
+def emu_conv(emu, data, mkh, mkw, kernels):
+    d, ks, n, kp, kh, kw = util.Oracle._prep(data, kernels)
+    H, W, F = d.shape
+    fh, fw = util.ceil16(H + mkh - 1), util.ceil16(W + mkw - 1)
+    outs = [np.full((fh, fw), 7e7, dtype=np.float32, order="F") for _ in range(n)]
+    op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    lh, lw = ctypes.c_int(), ctypes.c_int()
+    rc = emu.emu_conv_fft(ctypes.c_void_p(d.ctypes.data), H, W, F, mkh, mkw, n, kp, kh, kw, op,
+                          ctypes.byref(lh), ctypes.byref(lw))
+    return rc, outs, (lh.value, lw.value)
+
+
+LENGTHS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 22, 26, 32, 33, 34, 40, 64, 66, 80, 88,
+           128, 136, 144, 256, 272, 528, 544, 1040, 1056, 1088, 2080, 2112, 4096, 4160, 4224, 2431, 245, 1001]
+
+
+@pytest.mark.parametrize("L", LENGTHS)
+def test_transform_1d(emu, L):
+    """in-place DIF forward / DIT inverse of fft_lds.hpp against numpy, through the plan's
+    digit-reversal table"""
+    assert emu.emu_length_supported(L)
+    rng = np.random.default_rng(L)
+    x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+    xi = np.ascontiguousarray(x).view(np.float32).copy()
+    xo = np.zeros(2 * L, np.float32)
+    assert emu.emu_fft1d(L, xi.ctypes.data_as(ctypes.c_void_p), xo.ctypes.data_as(ctypes.c_void_p), 0) == 0
+    ref = np.fft.fft(x.astype(np.complex128))
+    assert np.abs(xo.view(np.complex64) - ref).max() / np.abs(ref).max() < 2e-6
+    yo = np.zeros(2 * L, np.float32)
+    assert emu.emu_fft1d(L, xo.ctypes.data_as(ctypes.c_void_p), yo.ctypes.data_as(ctypes.c_void_p), 1) == 0
+    assert np.abs(yo.view(np.complex64) / L - x).max() / np.abs(x).max() < 2e-6
+
+
+def test_unsupported_prime_lengths(emu):
+    for L in (19, 23, 38, 4222, 1087):
+        assert not emu.emu_length_supported(L)
+
+
+@pytest.mark.parametrize("need,exact", [(286, 288), (1086, 1088), (4222, 4224), (4158, 4160), (2110, 2112), (73, 80),
+                                        (11, 16), (1, 16), (500, 512), (1000, 1008), (8191, 8192)])
+def test_choose_length(emu, need, exact):
+    for real_half in (0, 1):
+        L = emu.emu_choose_length(need, real_half, exact)
+        assert L >= need
+        assert emu.emu_length_supported(L // 2 if real_half else L)
+        if real_half:
+            assert L % 2 == 0
+        assert L <= 2 * need + 32
+
+
+def test_baseline_configs_use_the_reference_window(emu):
+    # every BASELINE config's ceil16 window factors into the engine's radices, so the internal
+    # transform equals the reference's circular modulus
+    for need, win in [(286, 288), (1086, 1088), (4222, 4224), (4158, 4160), (2110, 2112)]:
+        assert emu.emu_choose_length(need, 1, win) == win
+        assert emu.emu_choose_length(need, 0, win) == win
+
+
+@pytest.mark.parametrize("case", golden_util.golden_cases())
+def test_emulated_pipeline_matches_golden(emu, case):
+    data, mkh, mkw, kernels, expect = golden_util.load_case(case)
+    rc, got, _ = emu_conv(emu, data, mkh, mkw, kernels)
+    assert rc == 0
+    for g, e in zip(got, expect):
+        assert util.rel_err(g, e) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4, 3), (33, 47, 3, 7, 5, 2), (1, 1, 1, 1, 1, 1), (2, 3, 1, 1, 2, 1),
+                                   (5, 5, 2, 5, 5, 1), (17, 1, 1, 3, 1, 1), (1, 40, 2, 1, 9, 2), (300, 20, 1, 21, 3, 1),
+                                   (130, 260, 3, 12, 8, 2), (50, 60, 1, 19, 23, 1)])
+def test_emulated_pipeline_matches_oracle(emu, oracle, shape):
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape))
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(n)]
+    if n > 1:
+        ks[1] = rng.random((max(1, kh - 2), max(1, kw - 1), F), dtype=np.float32)   # ragged cell
+    rc, got, L = emu_conv(emu, data, kh, kw, ks)
+    assert rc == 0
+    assert L[0] >= H + kh - 1 and L[1] >= W + kw - 1 and L[0] % 2 == 0
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    for g, r in zip(got, ref):
+        assert util.rel_err(g, r) < 1e-5
+
+
+def test_emulated_oversize_kernel_policy(emu):
+    """kernel > MAXK: reproduced (circular, like the reference) when the transform is the ceil16
+    window, rejected otherwise"""
+    rng = np.random.default_rng(3)
+    data = rng.random((40, 20, 1), dtype=np.float32)          # window 48x32 == transform
+    rc, got, L = emu_conv(emu, data, 9, 13, [rng.random((12, 16, 1), dtype=np.float32)])
+    assert L == (48, 32) and rc == 0
+    data = rng.random((64, 8, 1), dtype=np.float32)           # window 80x16, transform 80x11
+    rc, _, L = emu_conv(emu, data, 10, 4, [rng.random((10, 6, 1), dtype=np.float32)])
+    assert L[1] != 16 and rc == -3
+
+
+# ---------------------------------------------------------------- the C-ABI library itself
+
+def declared_symbols():
+    hdr = open(os.path.join(util.ROOT, "include", "fftconv.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(fftconv_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_loads_and_exports_every_declared_symbol(fftconv):
+    lib = fftconv.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert set(syms) == set(fftconv.EXPORTED_SYMBOLS)
+    assert lib.fftconv_version().startswith(b"fftconv-mi355x")
+
+
+def test_fft_size16_abi(fftconv):
+    for n, want in [(1, 16), (16, 16), (17, 32), (4222, 4224), (73, 80)]:
+        assert fftconv.fft_size16(n) == want
+
+
+def test_argument_errors_need_no_gpu(fftconv):
+    data = np.zeros((8, 8, 2), np.float32)
+    k = np.zeros((3, 3, 2), np.float32)
+    with pytest.raises(fftconv.FFTConvError) as e:      # src/cudaConvolutionFFT.cu:72-73
+        fftconv.cudaConvolutionFFT(data, 3, 3, [k], [8, 8, 8])
+    assert e.value.status == -2 and e.value.identifier == "cudaConvFFTData:InvalidInput"
+    with pytest.raises(fftconv.FFTConvError) as e:      # :242 feature mismatch
+        fftconv.cudaConvolutionFFT(data, 3, 3, [np.zeros((3, 3, 1), np.float32)])
+    assert e.value.status == -3
+    with pytest.raises(fftconv.FFTConvError):           # :64-65 kernel must be a cell
+        fftconv.cudaConvolutionFFT(data, 3, 3, k)
+    with pytest.raises(fftconv.FFTConvError):           # :51-54 single only
+        fftconv.cudaConvolutionFFT(data.astype(np.float64), 3, 3, [k])
+
+
+def test_compute_fails_loudly_without_gpu(fftconv):
+    """the product has no CPU fallback: on a box without a GPU every compute entry raises"""
+    if fftconv.device_count() > 0:
+        pytest.skip("a GPU is present")
+    data = np.zeros((8, 8, 1), np.float32)
+    with pytest.raises(fftconv.FFTConvError) as e:
+        fftconv.cudaConvolutionFFT(data, 3, 3, [np.zeros((3, 3, 1), np.float32)])
+    assert e.value.status in (-6, -7)
+    with pytest.raises(fftconv.FFTConvError):
+        fftconv.Plan(8, 8, 1, 3, 3)
