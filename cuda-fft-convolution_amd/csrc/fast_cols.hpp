@@ -1,0 +1,234 @@
+// fast_cols.hpp -- specialised output kernel (hot kernel #2): half-complex -> real inverse
+// transform along h of T columns per tile, straight into the caller's maps.
+//
+// Same job as cols_c2r_body (kernels_body.hpp) with the transform (M = R1*R2*R3 complex points,
+// Lh = 2M = FFT_H), the tile width T and the thread count fixed at compile time, and a
+// PERSISTENT workgroup: one workgroup per CU owns the whole LDS (T columns of M+1 bins plus all
+// tables), loops over tiles (kernel n, column tile) and software-pipelines them -- the gather of
+// the next tile is issued into registers before the current tile is transformed and lands in
+// LDS after its last stage has been read.  No run-time integer division, twiddles from LDS
+// tables (stage 2) or one table entry + power chain (stage 1), stage 3 on 16-byte LDS accesses.
+//
+// The rows of the intermediate Y arrive in the generic kernels' h-frequency order; `rowoff`
+// (precomputed per LDS position) redirects the gather, so this kernel is independent of the
+// radix sequence the producers use.
+#pragma once
+#include "butterflies.hpp"
+#include "fast_rows.hpp"  // power_chain, c32x2
+#include "fc_common.hpp"
+
+namespace fc {
+
+template <int M_, int R1_, int R2_, int R3_, int T_, int NT_>
+struct ColCfg {
+    static constexpr int M = M_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_, NT = NT_;
+    static constexpr int m1 = M / R1;            // stage-1 sub-length (= R2*R3)
+    static constexpr int NB1 = m1, NB2 = R1 * R3, NB3 = R1 * R2;  // butterflies per column
+    static constexpr int LP = ((M + 1 + 13) / 16) * 16 + 2;      // column pitch: >= M+1, == 2 mod 16
+    static constexpr int UPT = (M * T) / (2 * NT);               // 16-byte gather units per thread
+    static constexpr int NPAIR = M / 2 - 1;                      // ordinary pairs per column
+    static constexpr int RNDP = (NPAIR * T + NT - 1) / NT;
+    static constexpr int RND2 = (NB2 * T + NT - 1) / NT;
+    static constexpr int RND1 = (NB1 * T + NT - 1) / NT;
+    static constexpr int T2N = (R2 - 1) * R3;
+    // LDS image (c32 units): columns | stage-2 twiddles | stage-1 base twiddles | pair table
+    static constexpr int OFF_T2 = T * LP;
+    static constexpr int OFF_T1 = OFF_T2 + T2N;
+    static constexpr int OFF_PAIR = OFF_T1 + m1 + ((OFF_T1 + m1) & 1);  // 16-byte aligned
+    static constexpr int NPE = M / 2 + 1;                                 // pair entries (incl. DC, middle)
+    static constexpr int LDS_ELEMS = OFF_PAIR + 2 * NPE;                  // PairEntry = 2 c32
+    static_assert(R1 * R2 * R3 == M, "radices must multiply to M");
+    static_assert(M % 2 == 0 && T % 2 == 0, "even M and T");
+    static_assert(NB3 * T == NT, "one stage-3 butterfly per thread");
+    static_assert((M * T) % (2 * NT) == 0, "gather units must divide evenly");
+    static_assert(R3 % 2 == 0, "stage-3 runs are read 16 bytes at a time");
+    static_assert(LP >= M + 1 && LP % 16 == 2, "column pitch");
+    static_assert(LDS_ELEMS * 8 <= 160 * 1024, "LDS budget");
+};
+
+struct FastColsArgs {
+    const c32* Y;            // [n][i][y_pitch]
+    size_t y_kernel_stride;
+    int y_pitch;
+    float* out;              // kernel n at out + n*out_kernel_stride; (h, w) at w*fft_h + h
+    size_t out_kernel_stride;
+    int fft_h, fft_w;        // fft_h == 2M, fft_w % T == 0, every column < fft_w exists in Y
+    int tiles_per_kernel;    // fft_w / T
+    int ntiles;              // tiles_per_kernel * kernels in this launch
+    const int* rowoff;       // M+1 entries: Y row offset (row * y_pitch) feeding LDS position p
+    const c32* tw1;          // w_M^j, j < m1
+    const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
+    const PairEntry* pairs;  // NPE entries: [0] DC/Nyquist, [k] pair (k, M-k), [M/2] middle
+};
+
+template <class C>
+struct ColState {
+    c32x2 pre[C::UPT];   // gather of the next tile
+    c32x2 pre_ny;        // ... its Nyquist row (threads < T/2)
+    int off[C::UPT];     // Y row offsets of this thread's gather units (tile-independent)
+};
+
+template <class C, class Ctx>
+FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
+    constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
+    constexpr int T2 = T / 2;
+    using State = ColState<C>;
+    c32* tw2 = lds + C::OFF_T2;
+    c32* tw1 = lds + C::OFF_T1;
+    PairEntry* pairs = reinterpret_cast<PairEntry*>(lds + C::OFF_PAIR);
+
+    auto issue_gather = [&](int t, State& st, int tile) {
+        const int kernel = tile / g.tiles_per_kernel;
+        const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
+        const c32* Y = g.Y + (size_t)kernel * g.y_kernel_stride + w0;
+        static_for<0, C::UPT>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            const int e = t + NT * r;
+            st.pre[r] = *reinterpret_cast<const c32x2*>(Y + st.off[r] + 2 * (e % T2));
+        });
+        if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Y + g.rowoff[M] + 2 * t);
+    };
+    auto land_gather = [&](int t, State& st) {
+        static_for<0, C::UPT>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            const int e = t + NT * r;
+            const int p = e / T2, t2 = e % T2;
+            lds[(2 * t2) * LP + p] = st.pre[r].a;
+            lds[(2 * t2 + 1) * LP + p] = st.pre[r].b;
+        });
+        if (t < T2) {
+            lds[(2 * t) * LP + M] = st.pre_ny.a;
+            lds[(2 * t + 1) * LP + M] = st.pre_ny.b;
+        }
+    };
+
+    // prologue: tables into LDS, gather offsets into registers, first tile
+    ctx.phase([&](int t, State& st) {
+        for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
+        for (int i = t; i < m1; i += NT) tw1[i] = g.tw1[i];
+        for (int i = t; i < C::NPE; i += NT) pairs[i] = g.pairs[i];
+        static_for<0, C::UPT>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            st.off[r] = g.rowoff[(t + NT * r) / T2];
+        });
+        if (wg < g.ntiles) {
+            issue_gather(t, st, wg);
+            land_gather(t, st);
+        }
+    });
+
+    for (int tile = wg; tile < g.ntiles; tile += nwg) {
+        const int kernel = tile / g.tiles_per_kernel;
+        const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
+        const int next = tile + nwg;
+
+        // C1: issue the next tile's gather (lands after C4), then merge the half spectrum of
+        // this tile into the packed complex sequence, in place (table driven)
+        ctx.phase([&](int t, State& st) {
+            if (next < g.ntiles) issue_gather(t, st, next);
+            static_for<0, C::RNDP>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int idx = t + NT * r;
+                if (idx < C::NPAIR * T) {
+                    const int k = idx / T + 1, col = idx % T;
+                    c32* z = lds + col * LP;
+                    const PairEntry e = pairs[k];
+                    c32 xk = z[e.a], xm = z[e.b];
+                    c32 Ssum = mk(xk.x + xm.x, xk.y - xm.y);
+                    c32 D = mk(xk.x - xm.x, xk.y + xm.y);
+                    c32 G = cmulc(D, e.w);
+                    z[e.a] = mk(Ssum.x - G.y, Ssum.y + G.x);
+                    z[e.b] = mk(Ssum.x + G.y, -Ssum.y + G.x);
+                }
+            });
+            if (t < T) {  // DC / Nyquist
+                c32* z = lds + t * LP;
+                const PairEntry e = pairs[0];
+                float x0 = z[e.a].x, xm = z[e.b].x;
+                z[e.a] = mk(x0 + xm, x0 - xm);
+            } else if (t < 2 * T) {  // middle bin
+                c32* z = lds + (t - T) * LP;
+                const PairEntry e = pairs[M / 2];
+                c32 x = z[e.a];
+                z[e.a] = mk(2.f * x.x, -2.f * x.y);
+            }
+        });
+
+        // C2: inverse stage 3 (radix R3 on contiguous runs), one butterfly per thread
+        ctx.phase([&](int t, State&) {
+            const int col = t / C::NB3, q = t % C::NB3;
+            c32* p = lds + col * LP + q * R3;
+            c32 v[R3];
+            static_for<0, R3 / 2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                c32x2 w = *reinterpret_cast<const c32x2*>(p + 2 * h);
+                v[2 * h] = w.a;
+                v[2 * h + 1] = w.b;
+            });
+            Dft<R3, +1>::run(v);
+            static_for<0, R3 / 2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                c32x2 w;
+                w.a = v[2 * h];
+                w.b = v[2 * h + 1];
+                *reinterpret_cast<c32x2*>(p + 2 * h) = w;
+            });
+        });
+
+        // C3: inverse stage 2 (radix R2, sub-length R3)
+        ctx.phase([&](int t, State&) {
+            static_for<0, C::RND2>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int idx = t + NT * r;
+                if (idx < C::NB2 * T) {
+                    const int col = idx / C::NB2, u = idx % C::NB2;
+                    const int c1 = u / R3, b = u % R3;
+                    c32* p = lds + col * LP + c1 * m1 + b;
+                    c32 v[R2];
+                    v[0] = p[0];
+                    static_for<1, R2>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        v[c] = cmulc(p[c * R3], tw2[(c - 1) * R3 + b]);
+                    });
+                    Dft<R2, +1>::run(v);
+                    static_for<0, R2>([&](auto a_) {
+                        constexpr int a = decltype(a_)::value;
+                        p[a * R3] = v[a];
+                    });
+                }
+            });
+        });
+
+        // C4: inverse stage 1 straight to the map: out[w][2n], out[w][2n+1] = re, im of z[n]
+        float* out = g.out + (size_t)kernel * g.out_kernel_stride;
+        ctx.phase([&](int t, State&) {
+            static_for<0, C::RND1>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int idx = t + NT * r;
+                if (idx < C::NB1 * T) {
+                    const int col = idx / C::NB1, j = idx % C::NB1;
+                    const c32* p = lds + col * LP + j;
+                    c32 pw[R1];
+                    power_chain<R1>(tw1[j], pw);
+                    c32 v[R1];
+                    v[0] = p[0];
+                    static_for<1, R1>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        v[c] = cmulc(p[c * m1], pw[c]);
+                    });
+                    Dft<R1, +1>::run(v);
+                    c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.fft_h);
+                    static_for<0, R1>([&](auto a_) {
+                        constexpr int a = decltype(a_)::value;
+                        o[j + a * m1] = v[a];
+                    });
+                }
+            });
+        });
+
+        // C5: the prefetched tile lands in LDS
+        if (next < g.ntiles) ctx.phase([&](int t, State& st) { land_gather(t, st); });
+    }
+}
+
+}  // namespace fc

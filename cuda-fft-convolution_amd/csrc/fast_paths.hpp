@@ -1,0 +1,149 @@
+// fast_paths.hpp -- registry of the specialised (compile-time) kernel configurations.
+//
+// The generic kernels (kernels_body.hpp) handle every supported length; the configurations
+// listed here replace the two hot kernels for the transform lengths that matter (the BASELINE
+// configs), chosen so that every stage keeps >= 90 % of the lanes busy and the LDS budget allows
+// 3 waves per SIMD.  X(L, R1, R2, R3, NT, NZ2): see fast_rows.hpp.
+#pragma once
+#include <vector>
+
+#include "fast_cols.hpp"
+#include "fast_rows.hpp"
+#include "planner.hpp"
+
+namespace fc {
+
+// L = 4224 (cfg3, cfg5's 2112 handled separately): 8 x 24 x 22 with 192 threads per row:
+//   stage butterflies 528 / 176 / 192 -> 2.75 / 0.92 / 1.0 rounds of 192 lanes.
+#define FC_FAST_ROW_CONFIGS(X) \
+    X(4224, 8, 24, 22, 192, 6) \
+    X(4224, 8, 24, 22, 192, 24)
+
+struct FastRowsInfo {
+    bool ok = false;
+    int L = 0, R1 = 0, R2 = 0, R3 = 0, NT = 0;
+    int max_kw = 0;      // largest kernel width the fast kernel accepts
+    size_t lds_bytes = 0;
+};
+
+// Is there a fast row kernel for transform length L able to take kernels up to max_kw wide?
+inline FastRowsInfo fast_rows_lookup(int L, int max_kw) {
+    FastRowsInfo r;
+#define FC_X(LL, A, B, C, NTT, NZ)                                                        \
+    if (!r.ok && L == LL) {                                                               \
+        using Cfg = RowCfg<LL, A, B, C, NTT>;                                             \
+        constexpr int XR = row_x_rounds<Cfg>();                        \
+        int lim = Cfg::m1 < XR * NTT ? Cfg::m1 : XR * NTT;                                \
+        if (max_kw <= lim) {                                                              \
+            r.ok = true; r.L = LL; r.R1 = A; r.R2 = B; r.R3 = C; r.NT = NTT;              \
+            r.max_kw = lim; r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);           \
+        }                                                                                 \
+    }
+    FC_FAST_ROW_CONFIGS(FC_X)
+#undef FC_X
+    return r;
+}
+
+// Calls run.template go<Cfg, NZ2>() for the first listed configuration of length L whose NZ2
+// covers `nz2_needed` (configurations are listed with ascending NZ2).  false if there is none.
+template <class Runner>
+inline bool fast_rows_dispatch(int L, int nz2_needed, Runner&& run) {
+#define FC_X(LL, A, B, C, NTT, NZ)                              \
+    if (L == LL && nz2_needed <= NZ) {                          \
+        run.template go<RowCfg<LL, A, B, C, NTT>, NZ>();        \
+        return true;                                            \
+    }
+    FC_FAST_ROW_CONFIGS(FC_X)
+#undef FC_X
+    return false;
+}
+
+// Host tables of a fast row configuration.
+struct FastRowsTables {
+    Plan1D plan;               // radices (R1, R2, R3)
+    std::vector<c32> tw1;      // w_L^j, j < m1
+    std::vector<c32> tw2;      // stage-2 table
+    std::vector<int> relayout; // register-order index -> generic position (see relayout_rows_body)
+};
+
+inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D& generic) {
+    FastRowsTables t;
+    t.plan = make_plan1d_seq(fi.L, {fi.R1, fi.R2, fi.R3});
+    const int m1 = fi.L / fi.R1;
+    const StageDesc& s1 = t.plan.desc.st[0];
+    const StageDesc& s2 = t.plan.desc.st[1];
+    t.tw1.assign(t.plan.tw.begin() + s1.tw_off, t.plan.tw.begin() + s1.tw_off + m1);
+    t.tw2.assign(t.plan.tw.begin() + s2.tw_off, t.plan.tw.begin() + s2.tw_off + (fi.R2 - 1) * fi.R3);
+    const int NB3 = fi.R1 * fi.R2;
+    t.relayout.assign(fi.L, 0);
+    for (int k = 0; k < fi.L; k++) {
+        int p = t.plan.pos[k];
+        int q = p / fi.R3, a = p % fi.R3;
+        int ro = ((a >> 1) * NB3 + q) * 2 + (a & 1);
+        t.relayout[ro] = generic.pos[k];
+    }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Output (column) kernel configurations: X(M, R1, R2, R3, T, NT), see fast_cols.hpp.
+// M = 2112 (FFT_H = 4224, cfg3): 8 x 12 x 22, 8 columns per tile, 768 threads:
+//   stage butterflies per tile 2112 / 1408 / 768 -> 2.75 / 1.83 / 1.0 rounds of 768 lanes.
+// ---------------------------------------------------------------------------------------
+#define FC_FAST_COL_CONFIGS(X) \
+    X(2112, 8, 12, 22, 8, 768)
+
+struct FastColsInfo {
+    bool ok = false;
+    int M = 0, R1 = 0, R2 = 0, R3 = 0, T = 0, NT = 0;
+    size_t lds_bytes = 0;
+};
+
+inline FastColsInfo fast_cols_lookup(int M) {
+    FastColsInfo r;
+#define FC_X(MM, A, B, C, TT, NTT)                                                   \
+    if (!r.ok && M == MM) {                                                          \
+        using Cfg = ColCfg<MM, A, B, C, TT, NTT>;                                    \
+        r.ok = true; r.M = MM; r.R1 = A; r.R2 = B; r.R3 = C; r.T = TT; r.NT = NTT;   \
+        r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);                          \
+    }
+    FC_FAST_COL_CONFIGS(FC_X)
+#undef FC_X
+    return r;
+}
+
+template <class Runner>
+inline bool fast_cols_dispatch(int M, Runner&& run) {
+#define FC_X(MM, A, B, C, TT, NTT)                          \
+    if (M == MM) {                                          \
+        run.template go<ColCfg<MM, A, B, C, TT, NTT>>();    \
+        return true;                                        \
+    }
+    FC_FAST_COL_CONFIGS(FC_X)
+#undef FC_X
+    return false;
+}
+
+struct FastColsTables {
+    Plan1D plan;                   // radices (R1, R2, R3)
+    std::vector<c32> tw1, tw2;
+    std::vector<PairEntry> pairs;  // positions in the fast plan's order
+    std::vector<int> rowoff;       // M+1: Y row offset feeding LDS position p
+};
+
+inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& generic, int y_pitch) {
+    FastColsTables t;
+    t.plan = make_plan1d_seq(fi.M, {fi.R1, fi.R2, fi.R3});
+    const int m1 = fi.M / fi.R1;
+    const StageDesc& s1 = t.plan.desc.st[0];
+    const StageDesc& s2 = t.plan.desc.st[1];
+    t.tw1.assign(t.plan.tw.begin() + s1.tw_off, t.plan.tw.begin() + s1.tw_off + m1);
+    t.tw2.assign(t.plan.tw.begin() + s2.tw_off, t.plan.tw.begin() + s2.tw_off + (fi.R2 - 1) * fi.R3);
+    t.pairs = make_pair_table(t.plan);
+    t.rowoff.assign(fi.M + 1, 0);
+    for (int k = 0; k < fi.M; k++) t.rowoff[t.plan.pos[k]] = generic.pos[k] * y_pitch;
+    t.rowoff[fi.M] = fi.M * y_pitch;
+    return t;
+}
+
+}  // namespace fc

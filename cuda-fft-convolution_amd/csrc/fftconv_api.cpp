@@ -103,6 +103,13 @@ struct fftconv_plan {
     DevBuf<float> K;   // packed kernels staged on the device
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
+    DevBuf<c32> S0;    // image spectrum in generic order before the relayout (fast rows only)
+    DevBuf<c32> fr_tw1, fr_tw2;
+    DevBuf<int> fr_map;
+    DevBuf<c32> fc_tw1, fc_tw2;
+    DevBuf<PairEntry> fc_pairs;
+    DevBuf<int> fc_rowoff;
+    int num_cus = 256;
     long opt_batch_maps = 0;
     bool profile = false;
     std::vector<EventPair> pending;
@@ -155,6 +162,8 @@ struct fftconv_plan {
         pool.clear();
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
+        S0.release(); fr_tw1.release(); fr_tw2.release(); fr_map.release();
+        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release();
     }
 };
 
@@ -184,6 +193,9 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
         return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX,
                     "kernel %dx%d exceeds MAX_KERNEL %dx%d and the internal transform (%dx%d) is not the %dx%d window",
                     kh, kw, g.max_kh, g.max_kw, g.Lh, g.Lw, g.fft_h, g.fft_w);
+    if (g.fast_rows.ok && kw > g.fast_rows.max_kw)
+        return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel width %d exceeds what this plan's row kernel accepts (%d)", kw,
+                    g.fast_rows.max_kw);
     const size_t per_a = (size_t)g.F * g.rows * a_pitch_for(kw);  // c32 per kernel
     const size_t a_budget = (size_t)256 << 20;
     int nbA = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, a_budget / (per_a * sizeof(c32))));
@@ -207,14 +219,24 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
         if (int rc = p->prof_end()) return rc;
         for (int y0 = 0; y0 < na; y0 += nbY) {
             const int ny = std::min(nbY, na - y0);
-            SpectralRowsArgs sa = spectral_rows_args(g, p->t, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
             if (int rc = p->prof_begin(PK_SPECTRAL, ny)) return rc;
-            HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
+            if (g.fast_rows.ok) {
+                FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
+                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, p->stream));
+            } else {
+                SpectralRowsArgs sa = spectral_rows_args(g, p->t, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
+                HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
+            }
             if (int rc = p->prof_end()) return rc;
             float* obase = staged ? p->O.p : sink.packed + (size_t)(a0 + y0) * g.map_elems();
-            ColsC2RArgs ca = cols_c2r_args(g, p->t, p->d, p->Y.p, obase, g.map_elems());
             if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
-            HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));
+            if (g.fast_cols.ok) {
+                FastColsArgs fa = fast_cols_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
+                HIP_TRY(launch_fast_cols(g.M, fa, p->num_cus, p->stream));
+            } else {
+                ColsC2RArgs ca = cols_c2r_args(g, p->t, p->d, p->Y.p, obase, g.map_elems());
+                HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));
+            }
             if (int rc = p->prof_end()) return rc;
             if (staged) {
                 for (int j = 0; j < ny; j++) {
@@ -297,6 +319,39 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
         p->d.tw_m = p->tw_m.p;
         p->d.tw_w = p->tw_w.p;
         p->d.pairs = p->pairs.p;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, gpu_id) == hipSuccess && prop.multiProcessorCount > 0)
+                p->num_cus = prop.multiProcessorCount;
+        }
+        if (p->g.fast_cols.ok) {
+            const FastColsTables& ft = p->t.fcl;
+            if ((rc = p->fc_tw1.ensure(ft.tw1.size()))) break;
+            if ((rc = p->fc_tw2.ensure(ft.tw2.size()))) break;
+            if ((rc = p->fc_pairs.ensure(ft.pairs.size()))) break;
+            if ((rc = p->fc_rowoff.ensure(ft.rowoff.size()))) break;
+            if ((rc = cp(p->fc_tw1.p, ft.tw1.data(), ft.tw1.size() * sizeof(c32)))) break;
+            if ((rc = cp(p->fc_tw2.p, ft.tw2.data(), ft.tw2.size() * sizeof(c32)))) break;
+            if ((rc = cp(p->fc_pairs.p, ft.pairs.data(), ft.pairs.size() * sizeof(PairEntry)))) break;
+            if ((rc = cp(p->fc_rowoff.p, ft.rowoff.data(), ft.rowoff.size() * sizeof(int)))) break;
+            p->d.fc_tw1 = p->fc_tw1.p;
+            p->d.fc_tw2 = p->fc_tw2.p;
+            p->d.fc_pairs = p->fc_pairs.p;
+            p->d.fc_rowoff = p->fc_rowoff.p;
+        }
+        if (p->g.fast_rows.ok) {
+            const FastRowsTables& fr = p->t.fr;
+            if ((rc = p->fr_tw1.ensure(fr.tw1.size()))) break;
+            if ((rc = p->fr_tw2.ensure(fr.tw2.size()))) break;
+            if ((rc = p->fr_map.ensure(fr.relayout.size()))) break;
+            if ((rc = p->S0.ensure(p->g.spectrum_elems()))) break;
+            if ((rc = cp(p->fr_tw1.p, fr.tw1.data(), fr.tw1.size() * sizeof(c32)))) break;
+            if ((rc = cp(p->fr_tw2.p, fr.tw2.data(), fr.tw2.size() * sizeof(c32)))) break;
+            if ((rc = cp(p->fr_map.p, fr.relayout.data(), fr.relayout.size() * sizeof(int)))) break;
+            p->d.fr_tw1 = p->fr_tw1.p;
+            p->d.fr_tw2 = p->fr_tw2.p;
+            p->d.fr_relayout = p->fr_map.p;
+        }
     } while (0);
     if (rc) {
         p->release_all();
@@ -345,13 +400,20 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         HIP_TRY(hipMemcpyAsync(p->I.p, data, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
         dimg = p->I.p;
     }
-    ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, p->spec());
+    // with the fast row kernel the generic passes work in a scratch buffer and a final
+    // permutation writes the spectrum in the register order that kernel reads
+    c32* sgen = g.fast_rows.ok ? p->S0.p : p->spec();
+    ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_COLS, g.F)) return rc;
     HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
     if (int rc = p->prof_end()) return rc;
-    RowsFwdArgs ra = image_rows_args(g, p->t, p->d, p->spec());
+    RowsFwdArgs ra = image_rows_args(g, p->t, p->d, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_ROWS, g.F)) return rc;
     HIP_TRY(launch_rows_fwd(ra, g.F * g.rows, rows_threads(g), (size_t)g.Lw * sizeof(c32), p->stream));
+    if (g.fast_rows.ok) {
+        RelayoutArgs rl = relayout_args(g, p->d, sgen, p->spec());
+        HIP_TRY(launch_relayout_rows(rl, g.F * g.rows, p->stream));
+    }
     if (int rc = p->prof_end()) return rc;
     if (location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
     p->have_image = true;

@@ -35,7 +35,105 @@ __global__ void __launch_bounds__(512) k_cols_c2r(ColsC2RArgs a) {
     cols_c2r_body(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// ---- fast path -------------------------------------------------------------------------
+template <class State>
+struct DevPhaseCtx {
+    State st;
+    template <class F>
+    __device__ __forceinline__ void phase(F&& f) {
+        f((int)threadIdx.x, st);
+        __syncthreads();
+    }
+    template <class F>
+    __device__ __forceinline__ void phase_nosync(F&& f) {
+        f((int)threadIdx.x, st);
+    }
+};
+
+template <class Cfg, int NZ2, bool MULTIF>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows(FastRowsArgs a) {
+    DevPhaseCtx<RowState<Cfg, MULTIF>> ctx;
+    fast_rows_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+__global__ void __launch_bounds__(256) k_relayout_rows(RelayoutArgs a) {
+    DevCtx ctx{(int)threadIdx.x, (int)blockDim.x};
+    relayout_rows_body(ctx, a, (int)blockIdx.x);
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT, Cfg::NT / 256) k_fast_cols(FastColsArgs a) {
+    DevPhaseCtx<ColState<Cfg>> ctx;
+    fast_cols_body<Cfg>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+struct FastColsLauncher {
+    const FastColsArgs& a;
+    int max_wg;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg>
+    void go() {
+        static bool attr_set = false;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        if (!attr_set) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cols<Cfg>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (err != hipSuccess) return;
+            attr_set = true;
+        }
+        const int grid = a.ntiles < max_wg ? a.ntiles : max_wg;
+        hipLaunchKernelGGL((k_fast_cols<Cfg>), dim3(grid), dim3(Cfg::NT), lds, s, a);
+        err = hipGetLastError();
+    }
+};
+
+struct FastRowsLauncher {
+    const FastRowsArgs& a;
+    int rows, kernels;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg, int NZ2>
+    void go() {
+        if (a.F > 1) launch<Cfg, NZ2, true>();
+        else launch<Cfg, NZ2, false>();
+    }
+    template <class Cfg, int NZ2, bool MULTIF>
+    void launch() {
+        static bool attr_set = false;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        if (!attr_set) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows<Cfg, NZ2, MULTIF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (err != hipSuccess) return;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_fast_rows<Cfg, NZ2, MULTIF>), dim3(rows, kernels), dim3(Cfg::NT), lds, s, a);
+        err = hipGetLastError();
+    }
+};
+
 }  // namespace
+
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, hipStream_t s) {
+    if (rows <= 0 || kernels <= 0) return hipSuccess;
+    FastRowsLauncher l{a, rows, kernels, s};
+    if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+hipError_t launch_fast_cols(int M, const FastColsArgs& a, int max_workgroups, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    FastColsLauncher l{a, max_workgroups, s};
+    if (!fast_cols_dispatch(M, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+hipError_t launch_relayout_rows(const RelayoutArgs& a, int rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_relayout_rows, dim3(rows), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t kernels_init() {
     const int lim = 160 * 1024;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstddef>
 
+#include "fast_paths.hpp"
 #include "kernels_body.hpp"
 #include "planner.hpp"
 
@@ -29,6 +30,8 @@ struct Geometry {
     int lds_pitch = 0;         // c32 per LDS-resident column
     int T_cols = 1;            // columns per workgroup in the h-passes
     bool exact_window = false; // Lh == fft_h && Lw == fft_w: circular modulus equals the reference's
+    FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
+    FastColsInfo fast_cols;    // specialised output kernel, if one exists for M (needs the exact window)
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const { return (size_t)rows * y_pitch; }
     size_t map_elems() const { return (size_t)fft_h * fft_w; }
@@ -38,10 +41,12 @@ struct Tables {
     Plan1D pm;  // M-point complex transform (h direction)
     Plan1D pw;  // Lw-point complex transform (w direction)
     std::vector<PairEntry> pairs;
+    FastRowsTables fr;  // only if Geometry::fast_rows.ok
+    FastColsTables fcl; // only if Geometry::fast_cols.ok
 };
 
 // returns false if the sizes are invalid / unsupported
-inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw) {
+inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw, bool allow_fast = true) {
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
     g.fft_h = fft_size16(H + max_kh - 1);
@@ -64,6 +69,11 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     t.pm = make_plan1d(g.M);
     t.pw = make_plan1d(g.Lw);
     t.pairs = make_pair_table(t.pm);
+    g.fast_rows = allow_fast ? fast_rows_lookup(g.Lw, max_kw) : FastRowsInfo();
+    if (g.fast_rows.ok) t.fr = make_fast_rows_tables(g.fast_rows, t.pw);
+    g.fast_cols = (allow_fast && g.exact_window) ? fast_cols_lookup(g.M) : FastColsInfo();
+    if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
+    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch);
     return true;
 }
 
@@ -72,6 +82,13 @@ struct DeviceTables {
     const c32* tw_m = nullptr;
     const c32* tw_w = nullptr;
     const PairEntry* pairs = nullptr;
+    const c32* fr_tw1 = nullptr;
+    const c32* fr_tw2 = nullptr;
+    const int* fr_relayout = nullptr;
+    const c32* fc_tw1 = nullptr;
+    const c32* fc_tw2 = nullptr;
+    const PairEntry* fc_pairs = nullptr;
+    const int* fc_rowoff = nullptr;
 };
 
 // image columns: planes = F, columns = W, valid samples = H
@@ -116,6 +133,37 @@ inline SpectralRowsArgs spectral_rows_args(const Geometry& g, const Tables& t, c
     a.F = g.F; a.fd = t.pw.desc; a.tw = d.tw_w;
     return a;
 }
+
+// fast spectral rows (S in register order)
+inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, const c32* A, int kw, const c32* S, c32* Y) {
+    FastRowsArgs a{};
+    a.A = A; a.a_pitch = a_pitch_for(kw); a.a_feat_stride = (size_t)g.rows * a.a_pitch;
+    a.a_kernel_stride = (size_t)g.F * a.a_feat_stride; a.kw = kw;
+    a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
+    a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
+    a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
+    return a;
+}
+
+// image spectrum: generic position order (src) -> register order (dst), all F*rows rows
+inline RelayoutArgs relayout_args(const Geometry& g, const DeviceTables& d, const c32* src, c32* dst) {
+    RelayoutArgs a{};
+    a.src = src; a.dst = dst; a.src_pitch = g.s_pitch; a.dst_pitch = g.s_pitch; a.n = g.Lw; a.map = d.fr_relayout;
+    return a;
+}
+
+// fast output columns: nk kernels of the current batch
+inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, const c32* Y, float* out,
+                                   size_t out_kernel_stride, int nk) {
+    FastColsArgs a{};
+    a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch;
+    a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
+    a.tiles_per_kernel = g.fft_w / g.fast_cols.T; a.ntiles = a.tiles_per_kernel * nk;
+    a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
+    return a;
+}
+
+inline int fast_rows_nz2(const Geometry& g, int kw) { return (kw + g.fast_rows.R3 - 1) / g.fast_rows.R3; }
 
 inline ColsC2RArgs cols_c2r_args(const Geometry& g, const Tables& t, const DeviceTables& d,
                                  const c32* Y, float* out, size_t out_kernel_stride) {

@@ -106,10 +106,11 @@ struct Plan1D {
     std::vector<int> pos;  // pos[k] = LDS position of forward-transform bin k
 };
 
-inline Plan1D make_plan1d(int L) {
+// Plan for an explicit radix sequence (product must be L).
+inline Plan1D make_plan1d_seq(int L, const std::vector<int>& radices) {
     Plan1D p;
     p.L = L;
-    p.radices = factorize(L);
+    p.radices = radices;
     p.desc.L = L;
     p.desc.ns = (int)p.radices.size();
     int n = L;
@@ -145,6 +146,8 @@ inline Plan1D make_plan1d(int L) {
     }
     return p;
 }
+
+inline Plan1D make_plan1d(int L) { return make_plan1d_seq(L, factorize(L)); }
 
 // Pair table for the real <-> half-complex conversion around a complex transform of length M
 // (real length N = 2M).  Entry 0 is the DC/Nyquist item (a = pos(0), b = M: the extra slot);

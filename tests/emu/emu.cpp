@@ -19,6 +19,59 @@ struct HostCtx {
     int tid = 0, nthreads = 1;
     void sync() const {}
 };
+
+// Phase-structured bodies (fast_rows.hpp): every phase is run for all NT threads before the
+// next one starts, with one State per emulated thread.
+template <class State>
+struct HostPhaseCtx {
+    int NT;
+    std::vector<State> st;
+    explicit HostPhaseCtx(int nt) : NT(nt), st(nt) {}
+    template <class F>
+    void phase(F&& f) {
+        for (int t = 0; t < NT; t++) f(t, st[t]);
+    }
+    template <class F>
+    void phase_nosync(F&& f) {
+        for (int t = 0; t < NT; t++) f(t, st[t]);
+    }
+};
+
+struct EmuFastRows {
+    const FastRowsArgs& a;
+    c32* lds;
+    int rows;
+    template <class Cfg, int NZ2>
+    void go() {
+        for (int r = 0; r < rows; r++) {
+            // poison the LDS image so that reads of never-written cells show up
+            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+            if (a.F > 1) {
+                HostPhaseCtx<RowState<Cfg, true>> ctx(Cfg::NT);
+                fast_rows_body<Cfg, NZ2, true>(ctx, lds, a, r, 0);
+            } else {
+                HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
+                fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, r, 0);
+            }
+        }
+    }
+};
+
+struct EmuFastCols {
+    const FastColsArgs& a;
+    c32* lds;
+    int nwg;
+    template <class Cfg>
+    void go() {
+        for (int wg = 0; wg < nwg; wg++) {
+            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+            HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
+            fast_cols_body<Cfg>(ctx, lds, a, wg, nwg);
+        }
+    }
+};
+
+bool g_allow_fast = true;
 }  // namespace
 
 extern "C" {
@@ -27,7 +80,7 @@ extern "C" {
 long emu_spectrum_elems(int H, int W, int F, int max_kh, int max_kw) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
     return (long)g.spectrum_elems();
 }
 
@@ -35,7 +88,7 @@ long emu_spectrum_elems(int H, int W, int F, int max_kh, int max_kw) {
 int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int max_kw, float* spec_out) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
     DeviceTables d;
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
@@ -50,6 +103,12 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
         for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
     RowsFwdArgs ra = image_rows_args(g, t, d, S);
     for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
+    if (g.fast_rows.ok) {  // generic position order -> register order of the fast row kernel
+        std::vector<c32> tmp(S, S + g.spectrum_elems());
+        d.fr_relayout = t.fr.relayout.data();
+        RelayoutArgs rl = relayout_args(g, d, tmp.data(), S);
+        for (int r = 0; r < F * g.rows; r++) relayout_rows_body(ctx, rl, r);
+    }
     return 0;
 }
 
@@ -58,7 +117,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
                           const float* const* kernels, const int* kh, const int* kw, float* const* out) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
     DeviceTables d;
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
@@ -76,10 +135,29 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
         ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
         for (int plane = 0; plane < F; plane++)
             for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
-        SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
-        for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
-        ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
-        for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
+        if (g.fast_rows.ok) {
+            if (kw[k] > g.fast_rows.max_kw) return -4;
+            d.fr_tw1 = t.fr.tw1.data();
+            d.fr_tw2 = t.fr.tw2.data();
+            FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
+            EmuFastRows run{fa, lds.data(), g.rows};
+            if (!fast_rows_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
+        } else {
+            SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
+            for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
+        }
+        if (g.fast_cols.ok) {
+            d.fc_tw1 = t.fcl.tw1.data();
+            d.fc_tw2 = t.fcl.tw2.data();
+            d.fc_pairs = t.fcl.pairs.data();
+            d.fc_rowoff = t.fcl.rowoff.data();
+            FastColsArgs fa = fast_cols_args(g, d, Y.data(), out[k], 0, 1);
+            EmuFastCols run{fa, lds.data(), 3};   // 3 persistent workgroups share the tiles
+            if (!fast_cols_dispatch(g.M, run)) return -6;
+        } else {
+            ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
+            for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
+        }
     }
     return 0;
 }
@@ -91,7 +169,7 @@ int emu_conv_fft(const float* data, int H, int W, int F, int max_kh, int max_kw,
                  int* lh_out, int* lw_out) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
     if (lh_out) *lh_out = g.Lh;
     if (lw_out) *lw_out = g.Lw;
     std::vector<float> spec(2 * g.spectrum_elems());
@@ -115,6 +193,16 @@ int emu_fft1d(int L, const float* xin /* 2L floats */, float* xout /* 2L floats 
         for (int i = 0; i < L; i++) { xout[2 * i] = buf[i].x; xout[2 * i + 1] = buf[i].y; }
     }
     return 0;
+}
+
+// 0: force the generic kernels everywhere; 1: use the specialised kernels where they exist
+void emu_allow_fast(int on) { g_allow_fast = on != 0; }
+// 1 if a plan of these sizes would use the fast spectral-row kernel
+int emu_uses_fast_rows(int H, int W, int F, int max_kh, int max_kw) {
+    Geometry g;
+    Tables t;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    return (g.fast_rows.ok ? 1 : 0) | (g.fast_cols.ok ? 2 : 0);
 }
 
 int emu_choose_length(int need, int real_half, int exact) { return choose_length(need, real_half != 0, exact); }
