@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfftconv.so")
+LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, "libfftconv.so")  # FFTCONV_LIB: kernel experiments
 
 HOST, DEVICE = 0, 1
 MEX_ERROR_ID = "cudaConvFFTData:InvalidInput"  # src/cudaConvolutionFFT.cu:30

@@ -17,6 +17,10 @@
 #include "fast_rows.hpp"  // power_chain, c32x2
 #include "fc_common.hpp"
 
+#ifndef FC_COLS_DBG
+#define FC_COLS_DBG 0   // timing experiments only (wrong results): 1 skip pair pass, 2 no barriers between stages, 4 no gather loads, 8 no stores
+#endif
+
 namespace fc {
 
 template <int M_, int R1_, int R2_, int R3_, int T_, int NT_>
@@ -55,6 +59,8 @@ struct FastColsArgs {
     int fft_h, fft_w;        // fft_h == 2M, fft_w % T == 0, every column < fft_w exists in Y
     int tiles_per_kernel;    // fft_w / T
     int ntiles;              // tiles_per_kernel * kernels in this launch
+    int y_tiled;             // 1: Y is tiled [w / TL][p][TL] in this kernel's LDS order (fast_rows.hpp)
+    int y_tile_elems;        // (M+1) * TL
     const int* rowoff;       // M+1 entries: Y row offset (row * y_pitch) feeding LDS position p
     const c32* tw1;          // w_M^j, j < m1
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
@@ -77,16 +83,36 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     c32* tw1 = lds + C::OFF_T1;
     PairEntry* pairs = reinterpret_cast<PairEntry*>(lds + C::OFF_PAIR);
 
+    // Tile order.  Adjacent column tiles share every 128-byte line of Y (a tile row is 64 bytes),
+    // so they should be gathered at the same time through the same L2: workgroups b and b+8 sit
+    // on the same XCD (round-robin dispatch; a speed assumption only), hence workgroup
+    // wg = 8*slot + xcd takes tile (iter*nwg + xcd*(nwg/8) + slot) -- each XCD walks a contiguous
+    // run of tiles.  Falls back to the plain order when nwg is not a multiple of 8.
+    const int per_xcd = nwg / 8;
+    const int first_tile = (nwg % 8 == 0) ? (wg % 8) * per_xcd + wg / 8 : wg;
+
     auto issue_gather = [&](int t, State& st, int tile) {
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
-        const c32* Y = g.Y + (size_t)kernel * g.y_kernel_stride + w0;
-        static_for<0, C::UPT>([&](auto r_) {
-            constexpr int r = decltype(r_)::value;
-            const int e = t + NT * r;
-            st.pre[r] = *reinterpret_cast<const c32x2*>(Y + st.off[r] + 2 * (e % T2));
-        });
-        if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Y + g.rowoff[M] + 2 * t);
+        if (g.y_tiled) {   // one contiguous block per tile, rows already in LDS order
+            static_assert(Y_TILE_W % T == 0, "layout tile must hold whole kernel tiles");
+            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 / Y_TILE_W) * g.y_tile_elems + (w0 % Y_TILE_W);
+            static_for<0, C::UPT>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int e = t + NT * r;
+                if constexpr (!(FC_COLS_DBG & 4))
+                    st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + (e / T2) * Y_TILE_W + 2 * (e % T2));
+            });
+            if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Yt + M * Y_TILE_W + 2 * t);
+        } else {
+            const c32* Y = g.Y + (size_t)kernel * g.y_kernel_stride + w0;
+            static_for<0, C::UPT>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int e = t + NT * r;
+                if constexpr (!(FC_COLS_DBG & 4)) st.pre[r] = *reinterpret_cast<const c32x2*>(Y + st.off[r] + 2 * (e % T2));
+            });
+            if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Y + g.rowoff[M] + 2 * t);
+        }
     };
     auto land_gather = [&](int t, State& st) {
         static_for<0, C::UPT>([&](auto r_) {
@@ -111,13 +137,13 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             constexpr int r = decltype(r_)::value;
             st.off[r] = g.rowoff[(t + NT * r) / T2];
         });
-        if (wg < g.ntiles) {
-            issue_gather(t, st, wg);
+        if (first_tile < g.ntiles) {
+            issue_gather(t, st, first_tile);
             land_gather(t, st);
         }
     });
 
-    for (int tile = wg; tile < g.ntiles; tile += nwg) {
+    for (int tile = first_tile; tile < g.ntiles; tile += nwg) {
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
         const int next = tile + nwg;
@@ -126,6 +152,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         // this tile into the packed complex sequence, in place (table driven)
         ctx.phase([&](int t, State& st) {
             if (next < g.ntiles) issue_gather(t, st, next);
+            if constexpr (!(FC_COLS_DBG & 1))
             static_for<0, C::RNDP>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int idx = t + NT * r;
@@ -155,7 +182,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         });
 
         // C2: inverse stage 3 (radix R3 on contiguous runs), one butterfly per thread
-        ctx.phase([&](int t, State&) {
+        ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
             const int col = t / C::NB3, q = t % C::NB3;
             c32* p = lds + col * LP + q * R3;
             c32 v[R3];
@@ -176,7 +203,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         });
 
         // C3: inverse stage 2 (radix R2, sub-length R3)
-        ctx.phase([&](int t, State&) {
+        ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int idx = t + NT * r;
@@ -220,7 +247,8 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.fft_h);
                     static_for<0, R1>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
-                        o[j + a * m1] = v[a];
+                        if constexpr (!(FC_COLS_DBG & 8)) o[j + a * m1] = v[a];
+                        else if (v[a].x == 1.2345e-30f) o[j + a * m1] = v[a];
                     });
                 }
             });

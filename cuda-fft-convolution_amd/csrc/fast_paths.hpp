@@ -129,6 +129,7 @@ struct FastColsTables {
     std::vector<c32> tw1, tw2;
     std::vector<PairEntry> pairs;  // positions in the fast plan's order
     std::vector<int> rowoff;       // M+1: Y row offset feeding LDS position p
+    std::vector<int> tile_row_of;  // M+1: generic spectrum row i -> row of the tiled intermediate (= LDS position)
 };
 
 inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& generic, int y_pitch) {
@@ -143,6 +144,9 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
     t.rowoff.assign(fi.M + 1, 0);
     for (int k = 0; k < fi.M; k++) t.rowoff[t.plan.pos[k]] = generic.pos[k] * y_pitch;
     t.rowoff[fi.M] = fi.M * y_pitch;
+    t.tile_row_of.assign(fi.M + 1, 0);
+    for (int k = 0; k < fi.M; k++) t.tile_row_of[generic.pos[k]] = t.plan.pos[k];
+    t.tile_row_of[fi.M] = fi.M;
     return t;
 }
 

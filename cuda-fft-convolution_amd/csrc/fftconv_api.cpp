@@ -108,7 +108,7 @@ struct fftconv_plan {
     DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
-    DevBuf<int> fc_rowoff;
+    DevBuf<int> fc_rowoff, fc_tile_row_of;
     int num_cus = 256;
     long opt_batch_maps = 0;
     bool profile = false;
@@ -163,7 +163,7 @@ struct fftconv_plan {
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
         S0.release(); fr_tw1.release(); fr_tw2.release(); fr_map.release();
-        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release();
+        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release();
     }
 };
 
@@ -338,6 +338,9 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
             p->d.fc_tw2 = p->fc_tw2.p;
             p->d.fc_pairs = p->fc_pairs.p;
             p->d.fc_rowoff = p->fc_rowoff.p;
+            if ((rc = p->fc_tile_row_of.ensure(ft.tile_row_of.size()))) break;
+            if ((rc = cp(p->fc_tile_row_of.p, ft.tile_row_of.data(), ft.tile_row_of.size() * sizeof(int)))) break;
+            p->d.fc_tile_row_of = p->fc_tile_row_of.p;
         }
         if (p->g.fast_rows.ok) {
             const FastRowsTables& fr = p->t.fr;

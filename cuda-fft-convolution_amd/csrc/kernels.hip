@@ -48,6 +48,11 @@ struct DevPhaseCtx {
     __device__ __forceinline__ void phase_nosync(F&& f) {
         f((int)threadIdx.x, st);
     }
+    template <bool NOSYNC, class F>
+    __device__ __forceinline__ void phase_dbg(F&& f) {
+        f((int)threadIdx.x, st);
+        if (!NOSYNC) __syncthreads();
+    }
 };
 
 template <class Cfg, int NZ2, bool MULTIF>

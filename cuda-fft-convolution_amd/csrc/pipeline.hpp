@@ -32,8 +32,12 @@ struct Geometry {
     bool exact_window = false; // Lh == fft_h && Lw == fft_w: circular modulus equals the reference's
     FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
     FastColsInfo fast_cols;    // specialised output kernel, if one exists for M (needs the exact window)
+    // tiled intermediate: both hot kernels fast and the window a whole number of layout tiles
+    bool y_tiled() const { return fast_rows.ok && fast_cols.ok && Y_TILE_W % fast_cols.T == 0 && fft_w % Y_TILE_W == 0; }
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
-    size_t y_elems_per_kernel() const { return (size_t)rows * y_pitch; }
+    size_t y_elems_per_kernel() const {
+        return y_tiled() ? (size_t)(fft_w / Y_TILE_W) * rows * Y_TILE_W : (size_t)rows * y_pitch;
+    }
     size_t map_elems() const { return (size_t)fft_h * fft_w; }
 };
 
@@ -89,6 +93,7 @@ struct DeviceTables {
     const c32* fc_tw2 = nullptr;
     const PairEntry* fc_pairs = nullptr;
     const int* fc_rowoff = nullptr;
+    const int* fc_tile_row_of = nullptr;
 };
 
 // image columns: planes = F, columns = W, valid samples = H
@@ -142,6 +147,7 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
     a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
     a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
+    a.y_row_of = g.y_tiled() ? d.fc_tile_row_of : nullptr; a.y_tile_elems = g.rows * Y_TILE_W;
     return a;
 }
 
@@ -160,6 +166,7 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
     a.tiles_per_kernel = g.fft_w / g.fast_cols.T; a.ntiles = a.tiles_per_kernel * nk;
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
+    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.rows * Y_TILE_W;
     return a;
 }
 

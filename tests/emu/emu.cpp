@@ -35,6 +35,10 @@ struct HostPhaseCtx {
     void phase_nosync(F&& f) {
         for (int t = 0; t < NT; t++) f(t, st[t]);
     }
+    template <bool NOSYNC, class F>
+    void phase_dbg(F&& f) {
+        for (int t = 0; t < NT; t++) f(t, st[t]);
+    }
 };
 
 struct EmuFastRows {
@@ -135,6 +139,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
         ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
         for (int plane = 0; plane < F; plane++)
             for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
+        if (g.fast_cols.ok) d.fc_tile_row_of = t.fcl.tile_row_of.data();
         if (g.fast_rows.ok) {
             if (kw[k] > g.fast_rows.max_kw) return -4;
             d.fr_tw1 = t.fr.tw1.data();
