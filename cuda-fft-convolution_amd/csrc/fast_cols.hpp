@@ -61,6 +61,10 @@ struct FastColsArgs {
     int ntiles;              // tiles_per_kernel * kernels in this launch
     int y_tiled;             // 1: Y is tiled [w / TL][p][TL] in this kernel's LDS order (fast_rows.hpp)
     int y_tile_elems;        // (M+1) * TL
+    int y_tile_shift;        // log2(TL), TL = 8 or 16 (tiled, not precombined)
+    int y_precombined;       // 1: Y holds the merged rows Z (fast_rows_pair.hpp): M rows per 8-column tile,
+                             //    contiguous, tile row u lands at LDS position lpos[u]; no pair pass here
+    const int* lpos;         // LDS landing position of tile row u (precombined: M entries; tiled: M+1)
     const int* rowoff;       // M+1 entries: Y row offset (row * y_pitch) feeding LDS position p
     const c32* tw1;          // w_M^j, j < m1
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
@@ -71,11 +75,16 @@ template <class C>
 struct ColState {
     c32x2 pre[C::UPT];   // gather of the next tile
     c32x2 pre_ny;        // ... its Nyquist row (threads < T/2)
-    int off[C::UPT];     // Y row offsets of this thread's gather units (tile-independent)
+    int off[C::UPT];     // Y row offsets (or, precombined, LDS landing positions) of this thread's gather units
 };
 
-template <class C, class Ctx>
+// MODE: layout of the intermediate -- 0 row-major [i][y_pitch], 1 tiled, 2 precombined + tiled
+// (see FastColsArgs).  A template parameter so that each variant carries only its own address
+// arithmetic (the kernel sits right at the 168-VGPR budget of 3 waves per SIMD).
+template <class C, int MODE, class Ctx>
 FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
+    constexpr bool PRE = (MODE == 2);
+    constexpr bool TILED = (MODE == 1);
     constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
     constexpr int T2 = T / 2;
     using State = ColState<C>;
@@ -89,21 +98,38 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     // wg = 8*slot + xcd takes tile (iter*nwg + xcd*(nwg/8) + slot) -- each XCD walks a contiguous
     // run of tiles.  Falls back to the plain order when nwg is not a multiple of 8.
     const int per_xcd = nwg / 8;
-    const int first_tile = (nwg % 8 == 0) ? (wg % 8) * per_xcd + wg / 8 : wg;
+    const int wg_x = (nwg % 8 == 0) ? (wg % 8) * per_xcd + wg / 8 : wg;
+    // Tile sequence of this workgroup: it-th tile.  With the 16-column tiled layout (two kernel
+    // tiles per 128-byte line) a workgroup takes both halves of a layout tile back to back, so
+    // the second half is served by L2 / Infinity Cache instead of a second HBM fetch.
+    const bool halves = false;   // measured slower than running the two halves concurrently on one XCD
+    auto tile_of = [&](int it) -> int {
+        if (halves) return ((it >> 1) * nwg + wg_x) * 2 + (it & 1);
+        return it * nwg + wg_x;
+    };
+    const int first_tile = tile_of(0);
 
     auto issue_gather = [&](int t, State& st, int tile) {
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
-        if (g.y_tiled) {   // one contiguous block per tile, rows already in LDS order
-            static_assert(Y_TILE_W % T == 0, "layout tile must hold whole kernel tiles");
-            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 / Y_TILE_W) * g.y_tile_elems + (w0 % Y_TILE_W);
+        if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
+            static_assert(!PRE || T == 8, "precombined tiles are 8 columns wide");
+            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 / T) * g.y_tile_elems;
+            static_for<0, C::UPT>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int e = t + NT * r;
+                if constexpr (!(FC_COLS_DBG & 4)) st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + 2 * e);
+            });
+        } else if constexpr (TILED) {   // rows of an 8- or 16-column layout tile
+            const int tw = 1 << g.y_tile_shift;   // layout tile width: a multiple of T
+            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 >> g.y_tile_shift) * g.y_tile_elems + (w0 & (tw - 1));
             static_for<0, C::UPT>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int e = t + NT * r;
                 if constexpr (!(FC_COLS_DBG & 4))
-                    st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + (e / T2) * Y_TILE_W + 2 * (e % T2));
+                    st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + ((e / T2) << g.y_tile_shift) + 2 * (e % T2));
             });
-            if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Yt + M * Y_TILE_W + 2 * t);
+            if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Yt + (M << g.y_tile_shift) + 2 * t);
         } else {
             const c32* Y = g.Y + (size_t)kernel * g.y_kernel_stride + w0;
             static_for<0, C::UPT>([&](auto r_) {
@@ -118,11 +144,12 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const int e = t + NT * r;
-            const int p = e / T2, t2 = e % T2;
+            const int t2 = e % T2;
+            const int p = (PRE || TILED) ? st.off[r] : e / T2;
             lds[(2 * t2) * LP + p] = st.pre[r].a;
             lds[(2 * t2 + 1) * LP + p] = st.pre[r].b;
         });
-        if (t < T2) {
+        if (!PRE && t < T2) {
             lds[(2 * t) * LP + M] = st.pre_ny.a;
             lds[(2 * t + 1) * LP + M] = st.pre_ny.b;
         }
@@ -132,10 +159,11 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     ctx.phase([&](int t, State& st) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
         for (int i = t; i < m1; i += NT) tw1[i] = g.tw1[i];
-        for (int i = t; i < C::NPE; i += NT) pairs[i] = g.pairs[i];
+        if constexpr (!PRE)
+            for (int i = t; i < C::NPE; i += NT) pairs[i] = g.pairs[i];
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            st.off[r] = g.rowoff[(t + NT * r) / T2];
+            st.off[r] = (PRE || TILED) ? g.lpos[(t + NT * r) / T2] : g.rowoff[(t + NT * r) / T2];
         });
         if (first_tile < g.ntiles) {
             issue_gather(t, st, first_tile);
@@ -143,18 +171,23 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         }
     });
 
-    for (int tile = first_tile; tile < g.ntiles; tile += nwg) {
+    for (int it = 0;; it++) {
+        const int tile = tile_of(it);
+        if (tile >= g.ntiles) break;
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
-        const int next = tile + nwg;
+        const int next = tile_of(it + 1);
 
         // C1: issue the next tile's gather (lands after C4), then merge the half spectrum of
         // this tile into the packed complex sequence, in place (table driven)
-        ctx.phase([&](int t, State& st) {
+        if constexpr (PRE) ctx.phase_nosync([&](int t, State& st) {
+            if (next < g.ntiles) issue_gather(t, st, next);
+        });
+        else ctx.phase([&](int t, State& st) {
             if (next < g.ntiles) issue_gather(t, st, next);
             if constexpr (!(FC_COLS_DBG & 1))
-            static_for<0, C::RNDP>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
+            FC_NOUNROLL
+            for (int r = 0; r < C::RNDP; r++) {   // not unrolled: keeps the register footprint small
                 const int idx = t + NT * r;
                 if (idx < C::NPAIR * T) {
                     const int k = idx / T + 1, col = idx % T;
@@ -167,7 +200,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     z[e.a] = mk(Ssum.x - G.y, Ssum.y + G.x);
                     z[e.b] = mk(Ssum.x + G.y, -Ssum.y + G.x);
                 }
-            });
+            }
             if (t < T) {  // DC / Nyquist
                 c32* z = lds + t * LP;
                 const PairEntry e = pairs[0];

@@ -9,6 +9,7 @@
 
 #include "fast_cols.hpp"
 #include "fast_rows.hpp"
+#include "fast_rows_pair.hpp"
 #include "planner.hpp"
 
 namespace fc {
@@ -112,6 +113,10 @@ inline FastColsInfo fast_cols_lookup(int M) {
     return r;
 }
 
+// Paired-row kernel: same configurations as the single-row kernel.
+template <class Runner>
+inline bool fast_rows_pair_dispatch(int L, int nz2_needed, Runner&& run) { return fast_rows_dispatch(L, nz2_needed, run); }
+
 template <class Runner>
 inline bool fast_cols_dispatch(int M, Runner&& run) {
 #define FC_X(MM, A, B, C, TT, NTT)                          \
@@ -129,10 +134,17 @@ struct FastColsTables {
     std::vector<c32> tw1, tw2;
     std::vector<PairEntry> pairs;  // positions in the fast plan's order
     std::vector<int> rowoff;       // M+1: Y row offset feeding LDS position p
-    std::vector<int> tile_row_of;  // M+1: generic spectrum row i -> row of the tiled intermediate (= LDS position)
+    std::vector<int> tile_row_of;  // M+1: generic spectrum row i -> row of the tiled intermediate
+    std::vector<int> tile_lpos;    // M+1: tile row -> LDS landing position in the output kernel
+    // precombined intermediate (fast_rows_pair.hpp): one RowPair per paired-row workgroup, and the
+    // LDS landing position of every tile row
+    std::vector<RowPair> row_pairs;  // M/2 + 1
+    std::vector<int> lpos;           // M
 };
 
-inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& generic, int y_pitch) {
+// row_order (tiled intermediate): 0 = tile rows in the output kernel's LDS order (sequential,
+// conflict-free landing); 1 = rows of workgroups i and i+8 adjacent (half-lines meet in one L2).
+inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& generic, int y_pitch, int row_order = 0) {
     FastColsTables t;
     t.plan = make_plan1d_seq(fi.M, {fi.R1, fi.R2, fi.R3});
     const int m1 = fi.M / fi.R1;
@@ -144,9 +156,51 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
     t.rowoff.assign(fi.M + 1, 0);
     for (int k = 0; k < fi.M; k++) t.rowoff[t.plan.pos[k]] = generic.pos[k] * y_pitch;
     t.rowoff[fi.M] = fi.M * y_pitch;
+    // Tiled (not precombined) intermediate: spectrum row i (= workgroup i of the single-row
+    // kernel) goes to tile row r(i) chosen so that workgroups i and i+8 -- same XCD under
+    // round-robin dispatch, running at about the same time -- write ADJACENT 64-byte tile rows,
+    // i.e. the two halves of one 128-byte line meet in that XCD's L2 before going to HBM.
     t.tile_row_of.assign(fi.M + 1, 0);
-    for (int k = 0; k < fi.M; k++) t.tile_row_of[generic.pos[k]] = t.plan.pos[k];
+    t.tile_lpos.assign(fi.M + 1, 0);
+    std::vector<int> bin_of_row(fi.M, 0);
+    for (int k = 0; k < fi.M; k++) bin_of_row[generic.pos[k]] = k;
+    const int full = (fi.M / 16) * 16;
+    for (int i = 0; i < fi.M; i++) {
+        int r = t.plan.pos[bin_of_row[i]];
+        if (row_order == 1) {
+            r = i;
+            if (i < full) r = 16 * (i / 16) + 2 * (i % 8) + ((i / 8) % 2);
+        }
+        t.tile_row_of[i] = r;
+        t.tile_lpos[r] = t.plan.pos[bin_of_row[i]];
+    }
     t.tile_row_of[fi.M] = fi.M;
+    t.tile_lpos[fi.M] = fi.M;
+    const int M = fi.M;
+    t.lpos.assign(M, 0);
+    for (int u = 0; u + 1 < M / 2; u++) {   // regular pairs k = u + 1
+        const int k = u + 1;
+        RowPair rp{};
+        rp.rowA = generic.pos[k]; rp.rowB = generic.pos[M - k];
+        rp.outA = 2 * u; rp.outB = 2 * u + 1; rp.kind = 0;
+        double ang = -2.0 * M_PI * (double)k / (double)(2 * M);
+        rp.w = mk((float)std::cos(ang), (float)std::sin(ang));
+        t.row_pairs.push_back(rp);
+        t.lpos[rp.outA] = t.plan.pos[k];
+        t.lpos[rp.outB] = t.plan.pos[M - k];
+    }
+    {   // DC + Nyquist -> Z_0
+        RowPair rp{};
+        rp.rowA = generic.pos[0]; rp.rowB = M; rp.outA = M - 2; rp.outB = -1; rp.kind = 1; rp.w = mk(1.f, 0.f);
+        t.row_pairs.push_back(rp);
+        t.lpos[rp.outA] = t.plan.pos[0];
+    }
+    {   // self-paired middle bin
+        RowPair rp{};
+        rp.rowA = generic.pos[M / 2]; rp.rowB = rp.rowA; rp.outA = M - 1; rp.outB = -1; rp.kind = 2; rp.w = mk(1.f, 0.f);
+        t.row_pairs.push_back(rp);
+        t.lpos[rp.outA] = t.plan.pos[M / 2];
+    }
     return t;
 }
 

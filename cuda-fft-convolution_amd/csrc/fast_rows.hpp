@@ -22,13 +22,7 @@
 #include "butterflies.hpp"
 #include "fc_common.hpp"
 
-#ifndef FC_Y_TILE_W
-#define FC_Y_TILE_W 16   // columns per tile of the tiled intermediate: 16 c32 = one 128-byte line per row
-#endif
-
 namespace fc {
-
-constexpr int Y_TILE_W = FC_Y_TILE_W;
 
 template <int L_, int R1_, int R2_, int R3_, int NT_>
 struct RowCfg {
@@ -70,11 +64,12 @@ struct FastRowsArgs {
     const c32* tw1;          // w_L^j, j in [0, m1)
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
     // tiled intermediate (used when the fast output kernel consumes it): element (row i, w) at
-    //   (w / TL) * y_tile_elems + y_row_of[i] * TL + (w % TL),   TL = FC_Y_TILE_W columns
+    //   (w / TL) * y_tile_elems + y_row_of[i] * TL + (w % TL),   TL = 1 << y_tile_shift columns (8 or 16)
     // so that a column tile of the output kernel is (part of) one contiguous block whose rows
     // are already in that kernel's LDS order.  y_row_of == nullptr: plain [i][y_pitch] rows.
     const int* y_row_of;
     int y_tile_elems;        // (M+1) * TL
+    int y_tile_shift;        // log2(TL)
 };
 
 template <class C, bool MULTIF>
@@ -246,7 +241,7 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
 
     // P5: inverse stage 1 straight to global memory (natural w order, coalesced per a)
     const bool tiled = g.y_row_of != nullptr;
-    c32* yrow = g.Y + (size_t)kernel * g.y_kernel_stride + (tiled ? (size_t)g.y_row_of[row] * Y_TILE_W : (size_t)row * g.y_pitch);
+    c32* yrow = g.Y + (size_t)kernel * g.y_kernel_stride + (tiled ? ((size_t)g.y_row_of[row] << g.y_tile_shift) : (size_t)row * g.y_pitch);
     ctx.phase_nosync([&](int t, State&) {
         static_for<0, C::RND1>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
@@ -265,7 +260,7 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
                     constexpr int a = decltype(a_)::value;
                     int w = j + a * m1;
                     if (w < g.wout) {
-                        if (tiled) yrow[(size_t)(w / Y_TILE_W) * g.y_tile_elems + (w % Y_TILE_W)] = v[a];
+                        if (tiled) yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))] = v[a];
                         else yrow[w] = v[a];
                     }
                 });

@@ -16,6 +16,14 @@
 #define FC_D inline
 #endif
 
+#if defined(__clang__)
+#define FC_NOUNROLL _Pragma("clang loop unroll(disable)")
+#elif defined(__GNUC__)
+#define FC_NOUNROLL _Pragma("GCC unroll 1")
+#else
+#define FC_NOUNROLL
+#endif
+
 namespace fc {
 
 struct alignas(8) c32 {

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -108,7 +109,8 @@ struct fftconv_plan {
     DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
-    DevBuf<int> fc_rowoff, fc_tile_row_of;
+    DevBuf<int> fc_rowoff, fc_tile_row_of, fc_lpos, fc_tile_lpos;
+    DevBuf<RowPair> fc_row_pairs;
     int num_cus = 256;
     long opt_batch_maps = 0;
     bool profile = false;
@@ -163,7 +165,7 @@ struct fftconv_plan {
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
         S0.release(); fr_tw1.release(); fr_tw2.release(); fr_map.release();
-        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release();
+        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release();
     }
 };
 
@@ -201,7 +203,9 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
     int nbA = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, a_budget / (per_a * sizeof(c32))));
     const size_t y_bytes = g.y_elems_per_kernel() * sizeof(c32);
     int nbY = (int)p->opt_batch_maps;
-    if (nbY <= 0) nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)96 << 20) / y_bytes));
+    // auto: enough maps per launch to amortise the last partially filled wave of workgroups
+    // (the two hot kernels run ~2 "rounds" of workgroups per map on 256 CUs), capped at 1.25 GiB
+    if (nbY <= 0) nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)1280 << 20) / y_bytes));
     nbY = std::min(nbY, nbA);
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
@@ -220,7 +224,10 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
         for (int y0 = 0; y0 < na; y0 += nbY) {
             const int ny = std::min(nbY, na - y0);
             if (int rc = p->prof_begin(PK_SPECTRAL, ny)) return rc;
-            if (g.fast_rows.ok) {
+            if (g.y_pre()) {
+                FastRowsPairArgs fa = fast_rows_pair_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
+                HIP_TRY(launch_fast_rows_pair(g.Lw, fast_rows_nz2(g, kw), fa, g.M / 2 + 1, ny, p->stream));
+            } else if (g.fast_rows.ok) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, p->stream));
             } else {
@@ -292,7 +299,10 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
     if (gpu_id >= ndev) return fail(FFTCONV_ERR_NO_DEVICE, "gpu_id %d out of range (%d devices)", gpu_id, ndev);
     fftconv_plan* p = new (std::nothrow) fftconv_plan();
     if (!p) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
-    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w)) {
+    int path_mode = 2;   // FFTCONV_PATH_MODE: tests and A/B runs only (pipeline.hpp Geometry::path_mode)
+    if (const char* e = getenv("FFTCONV_PATH_MODE")) path_mode = atoi(e);
+    if (path_mode < 0 || path_mode > 3) path_mode = 2;
+    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, path_mode)) {
         delete p;
         return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
                     "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform", data_h, data_w,
@@ -341,6 +351,15 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
             if ((rc = p->fc_tile_row_of.ensure(ft.tile_row_of.size()))) break;
             if ((rc = cp(p->fc_tile_row_of.p, ft.tile_row_of.data(), ft.tile_row_of.size() * sizeof(int)))) break;
             p->d.fc_tile_row_of = p->fc_tile_row_of.p;
+            if ((rc = p->fc_lpos.ensure(ft.lpos.size()))) break;
+            if ((rc = p->fc_row_pairs.ensure(ft.row_pairs.size()))) break;
+            if ((rc = cp(p->fc_lpos.p, ft.lpos.data(), ft.lpos.size() * sizeof(int)))) break;
+            if ((rc = cp(p->fc_row_pairs.p, ft.row_pairs.data(), ft.row_pairs.size() * sizeof(RowPair)))) break;
+            p->d.fc_lpos = p->fc_lpos.p;
+            if ((rc = p->fc_tile_lpos.ensure(ft.tile_lpos.size()))) break;
+            if ((rc = cp(p->fc_tile_lpos.p, ft.tile_lpos.data(), ft.tile_lpos.size() * sizeof(int)))) break;
+            p->d.fc_tile_lpos = p->fc_tile_lpos.p;
+            p->d.fc_row_pairs = p->fc_row_pairs.p;
         }
         if (p->g.fast_rows.ok) {
             const FastRowsTables& fr = p->t.fr;

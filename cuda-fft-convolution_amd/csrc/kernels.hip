@@ -5,6 +5,10 @@
 // is deliberately unused; see DESIGN.md for the algorithmic bytes per launch.
 #include "kernels.hpp"
 
+#ifndef FC_PAIR_XCD_REMAP
+#define FC_PAIR_XCD_REMAP 0   // 1: XCD-aware (pair, kernel) order for the paired-row kernel (measured slower)
+#endif
+
 namespace fc {
 namespace {
 
@@ -53,6 +57,16 @@ struct DevPhaseCtx {
         f((int)threadIdx.x, st);
         if (!NOSYNC) __syncthreads();
     }
+    // value the accessor designates in lane (this ^ 8): DPP row_ror:8 (rotate by 8 within each
+    // row of 16 lanes), no LDS involved
+    template <class Acc>
+    __device__ __forceinline__ c32 peer8(int, Acc&& acc) {
+        const c32 v = acc(st);
+        c32 r;
+        r.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x128, 0xf, 0xf, false));
+        r.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x128, 0xf, 0xf, false));
+        return r;
+    }
 };
 
 template <class Cfg, int NZ2, bool MULTIF>
@@ -66,11 +80,68 @@ __global__ void __launch_bounds__(256) k_relayout_rows(RelayoutArgs a) {
     relayout_rows_body(ctx, a, (int)blockIdx.x);
 }
 
-template <class Cfg>
+template <class Cfg, int MODE>
 __global__ void __launch_bounds__(Cfg::NT, Cfg::NT / 256) k_fast_cols(FastColsArgs a) {
     DevPhaseCtx<ColState<Cfg>> ctx;
-    fast_cols_body<Cfg>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
+    fast_cols_body<Cfg, MODE>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
 }
+
+template <class Cfg, int NZ2, bool MULTIF>
+__global__ void __launch_bounds__(2 * Cfg::NT, 3) k_fast_rows_pair(FastRowsPairArgs a) {
+    // Workgroup -> (row pair, kernel).  All kernels of a batch multiply by the SAME image-spectrum
+    // rows, so the workgroups that share a row pair should run back to back on one XCD and take
+    // the rows from its L2: blocks b and b+8 share an XCD (round-robin dispatch; speed only), so
+    // XCD x = b % 8 walks pairs x, x+8, ... with the kernel index running fastest.
+#if FC_PAIR_XCD_REMAP
+    const int b = (int)blockIdx.x;
+    const int xcd = b & 7, sq = b >> 3;
+    const int pl = sq / a.nk;
+    const int kernel = sq - pl * a.nk;
+    const int pair = pl * 8 + xcd;
+    if (pair >= a.npairs) return;
+#else
+    const int pair = (int)blockIdx.x, kernel = (int)blockIdx.y;
+#endif
+    DevPhaseCtx<RowPairState<Cfg, MULTIF>> ctx;
+    fast_rows_pair_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, pair, kernel);
+}
+
+#ifndef FC_PAIR_XCD_REMAP
+#define FC_PAIR_XCD_REMAP 0
+#endif
+
+struct FastRowsPairLauncher {
+    const FastRowsPairArgs& a;
+    int pairs, kernels;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg, int NZ2>
+    void go() {
+        if (a.r.F > 1) launch<Cfg, NZ2, true>();
+        else launch<Cfg, NZ2, false>();
+    }
+    template <class Cfg, int NZ2, bool MULTIF>
+    void launch() {
+        static bool attr_set = false;
+        const size_t lds = (size_t)(2 * (Cfg::L + 16) + Cfg::T2N + Cfg::m1) * sizeof(c32);
+        if (!attr_set) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows_pair<Cfg, NZ2, MULTIF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (err != hipSuccess) return;
+            attr_set = true;
+        }
+        FastRowsPairArgs aa = a;
+        aa.nk = kernels;
+        aa.npairs = pairs;
+#if FC_PAIR_XCD_REMAP
+        const dim3 grid(8 * ((pairs + 7) / 8) * kernels);
+#else
+        const dim3 grid(pairs, kernels);
+#endif
+        hipLaunchKernelGGL((k_fast_rows_pair<Cfg, NZ2, MULTIF>), grid, dim3(2 * Cfg::NT), lds, s, aa);
+        err = hipGetLastError();
+    }
+};
 
 struct FastColsLauncher {
     const FastColsArgs& a;
@@ -79,16 +150,22 @@ struct FastColsLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg>
     void go() {
+        if (a.y_precombined) launch<Cfg, 2>();
+        else if (a.y_tiled) launch<Cfg, 1>();
+        else launch<Cfg, 0>();
+    }
+    template <class Cfg, int PRE>
+    void launch() {
         static bool attr_set = false;
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
         if (!attr_set) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cols<Cfg>),
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cols<Cfg, PRE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (err != hipSuccess) return;
             attr_set = true;
         }
         const int grid = a.ntiles < max_wg ? a.ntiles : max_wg;
-        hipLaunchKernelGGL((k_fast_cols<Cfg>), dim3(grid), dim3(Cfg::NT), lds, s, a);
+        hipLaunchKernelGGL((k_fast_cols<Cfg, PRE>), dim3(grid), dim3(Cfg::NT), lds, s, a);
         err = hipGetLastError();
     }
 };
@@ -124,6 +201,13 @@ hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int
     if (rows <= 0 || kernels <= 0) return hipSuccess;
     FastRowsLauncher l{a, rows, kernels, s};
     if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+hipError_t launch_fast_rows_pair(int L, int nz2, const FastRowsPairArgs& a, int pairs, int kernels, hipStream_t s) {
+    if (pairs <= 0 || kernels <= 0) return hipSuccess;
+    FastRowsPairLauncher l{a, pairs, kernels, s};
+    if (!fast_rows_pair_dispatch(L, nz2, l)) return hipErrorInvalidValue;
     return l.err;
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 
 #include "fast_paths.hpp"
 #include "kernels_body.hpp"
@@ -32,11 +33,21 @@ struct Geometry {
     bool exact_window = false; // Lh == fft_h && Lw == fft_w: circular modulus equals the reference's
     FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
     FastColsInfo fast_cols;    // specialised output kernel, if one exists for M (needs the exact window)
+    // precombined + tiled intermediate: both hot kernels fast, 8-column tiles (fast_rows_pair.hpp)
+    bool y_pre() const { return path_mode >= 3 && fast_rows.ok && fast_cols.ok && fast_cols.T == 8 && fft_w % 8 == 0 && wout == fft_w; }
+    // 0 generic kernels only; 1 fast kernels, row-major intermediate; 2 (default) + tiled
+    // intermediate; 3 paired rows / precombined intermediate (measured slower on MI355X: the
+    // 6-wave workgroups hide latency worse).  The other modes exist for tests and A/B runs.
+    int path_mode = 2;
     // tiled intermediate: both hot kernels fast and the window a whole number of layout tiles
-    bool y_tiled() const { return fast_rows.ok && fast_cols.ok && Y_TILE_W % fast_cols.T == 0 && fft_w % Y_TILE_W == 0; }
+    bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
+    int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
+    int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
+    int y_row_order = 0;       // see make_fast_cols_tables
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
-        return y_tiled() ? (size_t)(fft_w / Y_TILE_W) * rows * Y_TILE_W : (size_t)rows * y_pitch;
+        if (y_pre()) return (size_t)(fft_w / 8) * M * 8;
+        return y_tiled() ? (size_t)(fft_w / y_tile_w) * rows * y_tile_w : (size_t)rows * y_pitch;
     }
     size_t map_elems() const { return (size_t)fft_h * fft_w; }
 };
@@ -50,7 +61,11 @@ struct Tables {
 };
 
 // returns false if the sizes are invalid / unsupported
-inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw, bool allow_fast = true) {
+inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw, int path_mode = 2) {
+    const bool allow_fast = path_mode > 0;
+    g.path_mode = path_mode;
+    if (const char* e = getenv("FFTCONV_TILE_W")) g.y_tile_w = (atoi(e) == 8) ? 8 : 16;        // A/B runs only
+    if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e) ? 1 : 0;
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
     g.fft_h = fft_size16(H + max_kh - 1);
@@ -77,7 +92,7 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (g.fast_rows.ok) t.fr = make_fast_rows_tables(g.fast_rows, t.pw);
     g.fast_cols = (allow_fast && g.exact_window) ? fast_cols_lookup(g.M) : FastColsInfo();
     if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
-    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch);
+    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch, g.y_row_order);
     return true;
 }
 
@@ -94,6 +109,9 @@ struct DeviceTables {
     const PairEntry* fc_pairs = nullptr;
     const int* fc_rowoff = nullptr;
     const int* fc_tile_row_of = nullptr;
+    const RowPair* fc_row_pairs = nullptr;
+    const int* fc_lpos = nullptr;
+    const int* fc_tile_lpos = nullptr;
 };
 
 // image columns: planes = F, columns = W, valid samples = H
@@ -147,7 +165,16 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
     a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
     a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
-    a.y_row_of = g.y_tiled() ? d.fc_tile_row_of : nullptr; a.y_tile_elems = g.rows * Y_TILE_W;
+    a.y_row_of = g.y_tiled() ? d.fc_tile_row_of : nullptr; a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    return a;
+}
+
+// paired rows -> precombined tiled intermediate (g.y_pre()); launch with M/2 + 1 workgroups per kernel
+inline FastRowsPairArgs fast_rows_pair_args(const Geometry& g, const DeviceTables& d, const c32* A, int kw, const c32* S, c32* Y) {
+    FastRowsPairArgs a{};
+    a.r = fast_rows_args(g, d, A, kw, S, Y);
+    a.r.y_row_of = nullptr; a.r.y_tile_elems = g.M * 8;
+    a.pairs = d.fc_row_pairs;
     return a;
 }
 
@@ -166,7 +193,9 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
     a.tiles_per_kernel = g.fft_w / g.fast_cols.T; a.ntiles = a.tiles_per_kernel * nk;
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
-    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.rows * Y_TILE_W;
+    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    a.y_precombined = g.y_pre() ? 1 : 0; a.lpos = g.y_pre() ? d.fc_lpos : d.fc_tile_lpos;
+    if (g.y_pre()) a.y_tile_elems = g.M * 8;
     return a;
 }
 

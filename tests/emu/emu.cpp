@@ -39,6 +39,11 @@ struct HostPhaseCtx {
     void phase_dbg(F&& f) {
         for (int t = 0; t < NT; t++) f(t, st[t]);
     }
+    // the GPU's lane exchange (DPP row_ror:8): the peer's value was produced in an earlier phase
+    template <class Acc>
+    c32 peer8(int t, Acc&& acc) {
+        return acc(st[t ^ 8]);
+    }
 };
 
 struct EmuFastRows {
@@ -61,6 +66,25 @@ struct EmuFastRows {
     }
 };
 
+struct EmuFastRowsPair {
+    const FastRowsPairArgs& a;
+    c32* lds;
+    int pairs;
+    template <class Cfg, int NZ2>
+    void go() {
+        for (int u = 0; u < pairs; u++) {
+            for (int i = 0; i < 2 * (Cfg::L + 16) + Cfg::T2N + Cfg::m1; i++) lds[i] = mk(1e30f, -1e30f);
+            if (a.r.F > 1) {
+                HostPhaseCtx<RowPairState<Cfg, true>> ctx(2 * Cfg::NT);
+                fast_rows_pair_body<Cfg, NZ2, true>(ctx, lds, a, u, 0);
+            } else {
+                HostPhaseCtx<RowPairState<Cfg, false>> ctx(2 * Cfg::NT);
+                fast_rows_pair_body<Cfg, NZ2, false>(ctx, lds, a, u, 0);
+            }
+        }
+    }
+};
+
 struct EmuFastCols {
     const FastColsArgs& a;
     c32* lds;
@@ -70,12 +94,14 @@ struct EmuFastCols {
         for (int wg = 0; wg < nwg; wg++) {
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
             HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
-            fast_cols_body<Cfg>(ctx, lds, a, wg, nwg);
+            if (a.y_precombined) fast_cols_body<Cfg, 2>(ctx, lds, a, wg, nwg);
+            else if (a.y_tiled) fast_cols_body<Cfg, 1>(ctx, lds, a, wg, nwg);
+            else fast_cols_body<Cfg, 0>(ctx, lds, a, wg, nwg);
         }
     }
 };
 
-bool g_allow_fast = true;
+int g_allow_fast = 2;   // path mode (pipeline.hpp Geometry::path_mode)
 }  // namespace
 
 extern "C" {
@@ -140,7 +166,19 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
         for (int plane = 0; plane < F; plane++)
             for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
         if (g.fast_cols.ok) d.fc_tile_row_of = t.fcl.tile_row_of.data();
-        if (g.fast_rows.ok) {
+        if (g.fast_cols.ok) {
+            d.fc_row_pairs = t.fcl.row_pairs.data();
+            d.fc_lpos = t.fcl.lpos.data();
+            d.fc_tile_lpos = t.fcl.tile_lpos.data();
+        }
+        if (g.y_pre()) {
+            if (kw[k] > g.fast_rows.max_kw) return -4;
+            d.fr_tw1 = t.fr.tw1.data();
+            d.fr_tw2 = t.fr.tw2.data();
+            FastRowsPairArgs fa = fast_rows_pair_args(g, d, A.data(), kw[k], S, Y.data());
+            EmuFastRowsPair run{fa, lds.data(), g.M / 2 + 1};
+            if (!fast_rows_pair_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
+        } else if (g.fast_rows.ok) {
             if (kw[k] > g.fast_rows.max_kw) return -4;
             d.fr_tw1 = t.fr.tw1.data();
             d.fr_tw2 = t.fr.tw2.data();
@@ -200,8 +238,8 @@ int emu_fft1d(int L, const float* xin /* 2L floats */, float* xout /* 2L floats 
     return 0;
 }
 
-// 0: force the generic kernels everywhere; 1: use the specialised kernels where they exist
-void emu_allow_fast(int on) { g_allow_fast = on != 0; }
+// path mode: 0 generic kernels only ... 3 (default) everything (pipeline.hpp Geometry::path_mode)
+void emu_allow_fast(int mode) { g_allow_fast = mode; }
 // 1 if a plan of these sizes would use the fast spectral-row kernel
 int emu_uses_fast_rows(int H, int W, int F, int max_kh, int max_kw) {
     Geometry g;
