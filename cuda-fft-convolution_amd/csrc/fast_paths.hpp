@@ -143,7 +143,8 @@ struct FastColsTables {
 };
 
 // row_order (tiled intermediate): 0 = tile rows in the output kernel's LDS order (sequential,
-// conflict-free landing); 1 = rows of workgroups i and i+8 adjacent (half-lines meet in one L2).
+// conflict-free landing); 1 = rows of workgroups i and i+8 adjacent (half-lines meet in one L2);
+// 2 = spectrum row order (rows i, i+1 adjacent: what the persistent row kernel writes back to back).
 inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& generic, int y_pitch, int row_order = 0) {
     FastColsTables t;
     t.plan = make_plan1d_seq(fi.M, {fi.R1, fi.R2, fi.R3});
@@ -170,6 +171,8 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
         if (row_order == 1) {
             r = i;
             if (i < full) r = 16 * (i / 16) + 2 * (i % 8) + ((i / 8) % 2);
+        } else if (row_order == 2) {
+            r = i;
         }
         t.tile_row_of[i] = r;
         t.tile_lpos[r] = t.plan.pos[bin_of_row[i]];

@@ -75,6 +75,17 @@ __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows(FastRowsArgs a) {
     fast_rows_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+template <class Cfg, int NZ2, bool MULTIF>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_persist(FastRowsArgs a, int rows, int total_items) {
+    // contiguous run of items per workgroup; the first (total % nwg) workgroups take one more
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int base = total_items / nwg, rem = total_items - base * nwg;
+    const int item0 = wg * base + (wg < rem ? wg : rem);
+    const int item1 = item0 + base + (wg < rem ? 1 : 0);
+    DevPhaseCtx<RowState<Cfg, MULTIF>> ctx;
+    fast_rows_persist_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, rows, item0, item1);
+}
+
 __global__ void __launch_bounds__(256) k_relayout_rows(RelayoutArgs a) {
     DevCtx ctx{(int)threadIdx.x, (int)blockDim.x};
     relayout_rows_body(ctx, a, (int)blockIdx.x);
@@ -174,11 +185,32 @@ struct FastRowsLauncher {
     const FastRowsArgs& a;
     int rows, kernels;
     hipStream_t s;
+    int persist_wgs = 0;   // > 0: persistent variant with that many workgroups
     hipError_t err = hipSuccess;
     template <class Cfg, int NZ2>
     void go() {
+        if (persist_wgs > 0) {
+            if (a.F > 1) launch_persist<Cfg, NZ2, true>();
+            else launch_persist<Cfg, NZ2, false>();
+            return;
+        }
         if (a.F > 1) launch<Cfg, NZ2, true>();
         else launch<Cfg, NZ2, false>();
+    }
+    template <class Cfg, int NZ2, bool MULTIF>
+    void launch_persist() {
+        static bool attr_set = false;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        if (!attr_set) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows_persist<Cfg, NZ2, MULTIF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (err != hipSuccess) return;
+            attr_set = true;
+        }
+        const int total = rows * kernels;
+        const int grid = total < persist_wgs ? total : persist_wgs;
+        hipLaunchKernelGGL((k_fast_rows_persist<Cfg, NZ2, MULTIF>), dim3(grid), dim3(Cfg::NT), lds, s, a, rows, total);
+        err = hipGetLastError();
     }
     template <class Cfg, int NZ2, bool MULTIF>
     void launch() {
@@ -197,9 +229,9 @@ struct FastRowsLauncher {
 
 }  // namespace
 
-hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, hipStream_t s) {
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, hipStream_t s) {
     if (rows <= 0 || kernels <= 0) return hipSuccess;
-    FastRowsLauncher l{a, rows, kernels, s};
+    FastRowsLauncher l{a, rows, kernels, s, persist_wgs};
     if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
     return l.err;
 }

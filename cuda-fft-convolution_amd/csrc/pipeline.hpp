@@ -44,6 +44,7 @@ struct Geometry {
     int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
     int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
     int y_row_order = 0;       // see make_fast_cols_tables
+    bool rows_persistent = false; // persistent variant of the fast single-row kernel (measured slower: kept for A/B)
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
         if (y_pre()) return (size_t)(fft_w / 8) * M * 8;
@@ -65,7 +66,8 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     const bool allow_fast = path_mode > 0;
     g.path_mode = path_mode;
     if (const char* e = getenv("FFTCONV_TILE_W")) g.y_tile_w = (atoi(e) == 8) ? 8 : 16;        // A/B runs only
-    if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e);
+    if (const char* e = getenv("FFTCONV_ROWS_PERSIST")) g.rows_persistent = atoi(e) != 0;
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
     g.fft_h = fft_size16(H + max_kh - 1);

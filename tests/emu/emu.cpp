@@ -50,8 +50,25 @@ struct EmuFastRows {
     const FastRowsArgs& a;
     c32* lds;
     int rows;
+    bool persist;
     template <class Cfg, int NZ2>
     void go() {
+        if (persist) {   // 5 persistent workgroups share the rows (uneven split on purpose)
+            const int nwg = 5, total = rows;
+            for (int wg = 0; wg < nwg; wg++) {
+                const int base = total / nwg, rem = total - base * nwg;
+                const int item0 = wg * base + (wg < rem ? wg : rem), item1 = item0 + base + (wg < rem ? 1 : 0);
+                for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+                if (a.F > 1) {
+                    HostPhaseCtx<RowState<Cfg, true>> ctx(Cfg::NT);
+                    fast_rows_persist_body<Cfg, NZ2, true>(ctx, lds, a, rows, item0, item1);
+                } else {
+                    HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
+                    fast_rows_persist_body<Cfg, NZ2, false>(ctx, lds, a, rows, item0, item1);
+                }
+            }
+            return;
+        }
         for (int r = 0; r < rows; r++) {
             // poison the LDS image so that reads of never-written cells show up
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
@@ -183,7 +200,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fr_tw1 = t.fr.tw1.data();
             d.fr_tw2 = t.fr.tw2.data();
             FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
-            EmuFastRows run{fa, lds.data(), g.rows};
+            EmuFastRows run{fa, lds.data(), g.rows, g.rows_persistent};
             if (!fast_rows_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
         } else {
             SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());

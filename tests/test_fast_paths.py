@@ -1,0 +1,128 @@
+"""Specialised ("fast") kernels: every path mode / layout variant must give the oracle's answer.
+CPU tier runs the kernel bodies through the host emulator; GPU tier (-m gpu) runs the HIP kernels
+through the C ABI with the same switches (FFTCONV_PATH_MODE etc. are read at plan creation)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+EMU_DIR = os.path.join(util.ROOT, "tests", "emu")
+
+# shapes whose transform hits the specialised configurations (L = 4224 rows, M = 2112 columns)
+ROW_SHAPES = [(20, 4096, 1, 5, 127, 2), (20, 4100, 2, 5, 120, 1), (12, 4000, 1, 3, 200, 1), (12, 3700, 3, 3, 500, 1)]
+COL_SHAPES = [(4200, 10, 2, 25, 7, 1), (4096, 24, 1, 127, 9, 2)]
+BOTH_SHAPE = (4096, 4096, 1, 127, 127, 1)
+VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent)
+    (0, 16, 0, 0), (1, 16, 0, 0), (1, 16, 0, 1), (2, 16, 0, 0), (2, 8, 0, 0), (2, 8, 1, 0), (2, 8, 2, 1), (2, 16, 2, 1), (3, 8, 0, 0)]
+
+
+def make_inputs(shape, seed):
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(seed)
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(n)]
+    if n > 1:
+        ks[1] = rng.random((max(1, kh - 1), max(1, kw // 4), F), dtype=np.float32)   # ragged cell
+    return data, ks
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["make", "-C", EMU_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return ctypes.CDLL(os.path.join(EMU_DIR, "libfftconv_emu.so"))
+
+
+def emu_conv(emu, data, mkh, mkw, kernels):
+    d, ks, n, kp, kh, kw = util.Oracle._prep(data, kernels)
+    H, W, F = d.shape
+    outs = [np.full((util.ceil16(H + mkh - 1), util.ceil16(W + mkw - 1)), 7e7, dtype=np.float32, order="F") for _ in range(n)]
+    op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    rc = emu.emu_conv_fft(ctypes.c_void_p(d.ctypes.data), H, W, F, mkh, mkw, n, kp, kh, kw, op, None, None)
+    return rc, outs
+
+
+def set_variant(monkeypatch, v):
+    mode, tw, ro, pers = v
+    monkeypatch.setenv("FFTCONV_TILE_W", str(tw))
+    monkeypatch.setenv("FFTCONV_ROW_ORDER", str(ro))
+    monkeypatch.setenv("FFTCONV_ROWS_PERSIST", str(pers))
+    monkeypatch.setenv("FFTCONV_PATH_MODE", str(mode))
+
+
+@pytest.mark.parametrize("shape", ROW_SHAPES + COL_SHAPES)
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_emulated_fast_kernels_one_dimension(emu, oracle, monkeypatch, shape, mode):
+    set_variant(monkeypatch, (mode, 16, 0, 0))
+    emu.emu_allow_fast(mode)
+    H, W, F, kh, kw, n = shape
+    assert emu.emu_uses_fast_rows(H, W, F, kh, kw) in (1, 2)      # exactly one of the two fast kernels applies
+    data, ks = make_inputs(shape, 17)
+    rc, got = emu_conv(emu, data, kh, kw, ks)
+    emu.emu_allow_fast(2)
+    assert rc == 0
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_emulated_fast_kernels_all_variants(emu, oracle, monkeypatch, variant):
+    """both hot kernels specialised (4224 x 4224 window): every intermediate layout"""
+    set_variant(monkeypatch, variant)
+    emu.emu_allow_fast(variant[0])
+    H, W, F, kh, kw, n = BOTH_SHAPE
+    assert emu.emu_uses_fast_rows(H, W, F, kh, kw) == (3 if variant[0] > 0 else 0)
+    data, ks = make_inputs(BOTH_SHAPE, 3)
+    rc, got = emu_conv(emu, data, kh, kw, ks)
+    emu.emu_allow_fast(2)
+    assert rc == 0
+    assert util.rel_err(got[0], oracle.conv_fft(data, kh, kw, ks)[0]) < 1e-5
+
+
+def test_fast_row_kernel_rejects_too_wide_kernels(emu, monkeypatch):
+    # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224); plans for
+    # wider MAX_KERNEL_W fall back to the generic kernel at plan time
+    assert emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) == 0
+
+
+# ------------------------------------------------------------------------------------ GPU tier
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_gpu_fast_kernels_all_variants(fftconv, oracle, monkeypatch, variant):
+    set_variant(monkeypatch, variant)
+    data, ks = make_inputs(BOTH_SHAPE, 5)
+    H, W, F, kh, kw, n = BOTH_SHAPE
+    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
+    assert util.rel_err(got[0], oracle.conv_fft(data, kh, kw, ks)[0]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ROW_SHAPES + COL_SHAPES)
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_gpu_fast_kernels_one_dimension(fftconv, oracle, monkeypatch, shape, mode):
+    set_variant(monkeypatch, (mode, 16, 0, 0))
+    H, W, F, kh, kw, n = shape
+    data, ks = make_inputs(shape, 23)
+    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_fast_kernels_many_maps_multi_feature(fftconv, oracle):
+    """batched launches (several maps per launch, F = 2) through the plan API on the fast path"""
+    H, W, F, kh, kw, n = 4100, 4090, 2, 120, 130, 5
+    data, ks = util.synth(41, H, W, F, kh, kw, n)
+    with fftconv.Plan(H, W, F, kh, kw) as p:
+        assert (p.info.transform_h, p.info.transform_w) == (4224, 4224)
+        p.set_image(data)
+        for batch in (0, 2):
+            p.set_option("batch_maps", batch)
+            got = p.convolve(ks)
+            ref = oracle.conv_fft(data, kh, kw, ks)
+            for g, r in zip(got, ref):
+                assert util.rel_err(g, r) < 1e-5
