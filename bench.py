@@ -179,7 +179,8 @@ def main():
         if dom and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.config, {}).get(dom)
+                per_map = tj.get(args.config, {}).get(dom)
+                traffic = per_map * per[dom]["units_per_launch"] if per_map else None
             except Exception:
                 traffic = None
         total_maps = nf * world
