@@ -56,7 +56,8 @@ struct FastColsArgs {
     int y_pitch;
     float* out;              // kernel n at out + n*out_kernel_stride; (h, w) at w*fft_h + h
     size_t out_kernel_stride;
-    int fft_h, fft_w;        // fft_h == 2M, fft_w % T == 0, every column < fft_w exists in Y
+    int fft_h, fft_w;        // output window: fft_h <= 2M (rows beyond it are cropped), fft_w % T == 0,
+                             // every column < fft_w exists in Y
     int tiles_per_kernel;    // fft_w / T
     int ntiles;              // tiles_per_kernel * kernels in this launch
     int y_tiled;             // 1: Y is tiled [w / TL][p][TL] in this kernel's LDS order (fast_rows.hpp)
@@ -113,7 +114,6 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
         if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
-            static_assert(!PRE || T == 8, "precombined tiles are 8 columns wide");
             const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 / T) * g.y_tile_elems;
             static_for<0, C::UPT>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
@@ -261,9 +261,10 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
 
         // C4: inverse stage 1 straight to the map: out[w][2n], out[w][2n+1] = re, im of z[n]
         float* out = g.out + (size_t)kernel * g.out_kernel_stride;
+        const int nout = g.fft_h >> 1;   // complex pairs per output column
         ctx.phase([&](int t, State&) {
-            static_for<0, C::RND1>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
+            FC_NOUNROLL
+            for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the prefetched tile stays in registers
                 const int idx = t + NT * r;
                 if (idx < C::NB1 * T) {
                     const int col = idx / C::NB1, j = idx % C::NB1;
@@ -280,11 +281,11 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.fft_h);
                     static_for<0, R1>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
-                        if constexpr (!(FC_COLS_DBG & 8)) o[j + a * m1] = v[a];
-                        else if (v[a].x == 1.2345e-30f) o[j + a * m1] = v[a];
+                        if constexpr (FC_COLS_DBG & 8) { if (v[a].x == 1.2345e-30f) o[j + a * m1] = v[a]; }
+                        else if (j + a * m1 < nout) o[j + a * m1] = v[a];
                     });
                 }
-            });
+            }
         });
 
         // C5: the prefetched tile lands in LDS

@@ -2,8 +2,8 @@
 //
 // The generic kernels (kernels_body.hpp) handle every supported length; the configurations
 // listed here replace the two hot kernels for the transform lengths that matter (the BASELINE
-// configs), chosen so that every stage keeps >= 90 % of the lanes busy and the LDS budget allows
-// 3 waves per SIMD.  X(L, R1, R2, R3, NT, NZ2): see fast_rows.hpp.
+// configs), chosen so that every stage keeps most lanes busy and the LDS budget allows
+// 3 waves per SIMD.  The planner prefers these lengths (planner.hpp: choose_length).
 #pragma once
 #include <vector>
 
@@ -14,15 +14,27 @@
 
 namespace fc {
 
-// L = 4224 (cfg3, cfg5's 2112 handled separately): 8 x 24 x 22 with 192 threads per row:
-//   stage butterflies 528 / 176 / 192 -> 2.75 / 0.92 / 1.0 rounds of 192 lanes.
-#define FC_FAST_ROW_CONFIGS(X) \
-    X(4224, 8, 24, 22, 192, 6) \
-    X(4224, 8, 24, 22, 192, 24)
+// X(L, R1, R2, R3, NT, RPW, NZ2): see fast_rows.hpp.  NT = 192 threads (3 waves) everywhere;
+// RPW rows per workgroup chosen so that RPW * R1 * R2 = 192 stage-3 butterflies fill the lanes.
+//   4224 = 8 x 24 x 22 (cfg3; cfg4's 4160 window also runs on it): butterflies 528 / 176 / 192
+//   2112 = 8 x 12 x 22, 2 rows (cfg5):                            528 / 352 / 192
+//   1152 = 6 x  8 x 24, 4 rows (cfg2's 1088 window):              768 / 576 / 192
+//    288 = 4 x  6 x 12, 8 rows (cfg1):                            576 / 384 / 192
+// Listed with ascending NZ2 per length (the dispatcher takes the first that covers the kernel).
+#define FC_FAST_ROW_CONFIGS(X)      \
+    X(4224, 8, 24, 22, 192, 1, 3)   \
+    X(4224, 8, 24, 22, 192, 1, 6)   \
+    X(4224, 8, 24, 22, 192, 1, 24)  \
+    X(2112, 8, 12, 22, 192, 2, 3)   \
+    X(2112, 8, 12, 22, 192, 2, 12)  \
+    X(1152, 6, 8, 24, 192, 4, 3)    \
+    X(1152, 6, 8, 24, 192, 4, 8)    \
+    X(288, 4, 6, 12, 192, 8, 3)     \
+    X(288, 4, 6, 12, 192, 8, 6)
 
 struct FastRowsInfo {
     bool ok = false;
-    int L = 0, R1 = 0, R2 = 0, R3 = 0, NT = 0;
+    int L = 0, R1 = 0, R2 = 0, R3 = 0, NT = 0, RPW = 1;
     int max_kw = 0;      // largest kernel width the fast kernel accepts
     size_t lds_bytes = 0;
 };
@@ -30,14 +42,12 @@ struct FastRowsInfo {
 // Is there a fast row kernel for transform length L able to take kernels up to max_kw wide?
 inline FastRowsInfo fast_rows_lookup(int L, int max_kw) {
     FastRowsInfo r;
-#define FC_X(LL, A, B, C, NTT, NZ)                                                        \
+#define FC_X(LL, A, B, C, NTT, RP, NZ)                                                    \
     if (!r.ok && L == LL) {                                                               \
-        using Cfg = RowCfg<LL, A, B, C, NTT>;                                             \
-        constexpr int XR = row_x_rounds<Cfg>();                        \
-        int lim = Cfg::m1 < XR * NTT ? Cfg::m1 : XR * NTT;                                \
-        if (max_kw <= lim) {                                                              \
-            r.ok = true; r.L = LL; r.R1 = A; r.R2 = B; r.R3 = C; r.NT = NTT;              \
-            r.max_kw = lim; r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);           \
+        using Cfg = RowCfg<LL, A, B, C, NTT, RP>;                                         \
+        if (max_kw <= Cfg::m1) {                                                          \
+            r.ok = true; r.L = LL; r.R1 = A; r.R2 = B; r.R3 = C; r.NT = NTT; r.RPW = RP;  \
+            r.max_kw = Cfg::m1; r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);       \
         }                                                                                 \
     }
     FC_FAST_ROW_CONFIGS(FC_X)
@@ -45,14 +55,31 @@ inline FastRowsInfo fast_rows_lookup(int L, int max_kw) {
     return r;
 }
 
+inline bool fast_rows_length(int L) { return fast_rows_lookup(L, 1).ok; }
+
 // Calls run.template go<Cfg, NZ2>() for the first listed configuration of length L whose NZ2
 // covers `nz2_needed` (configurations are listed with ascending NZ2).  false if there is none.
 template <class Runner>
 inline bool fast_rows_dispatch(int L, int nz2_needed, Runner&& run) {
-#define FC_X(LL, A, B, C, NTT, NZ)                              \
+#define FC_X(LL, A, B, C, NTT, RP, NZ)                          \
     if (L == LL && nz2_needed <= NZ) {                          \
-        run.template go<RowCfg<LL, A, B, C, NTT>, NZ>();        \
+        run.template go<RowCfg<LL, A, B, C, NTT, RP>, NZ>();    \
         return true;                                            \
+    }
+    FC_FAST_ROW_CONFIGS(FC_X)
+#undef FC_X
+    return false;
+}
+
+// Variants built on one-row-per-workgroup configurations only (paired rows, persistent).
+template <class Runner>
+inline bool fast_rows_rpw1_dispatch(int L, int nz2_needed, Runner&& run) {
+#define FC_X(LL, A, B, C, NTT, RP, NZ)                                      \
+    if constexpr (RP == 1) {                                                \
+        if (L == LL && nz2_needed <= NZ) {                                  \
+            run.template go<RowCfg<LL, A, B, C, NTT, RP>, NZ>();            \
+            return true;                                                    \
+        }                                                                   \
     }
     FC_FAST_ROW_CONFIGS(FC_X)
 #undef FC_X
@@ -91,8 +118,14 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 // M = 2112 (FFT_H = 4224, cfg3): 8 x 12 x 22, 8 columns per tile, 768 threads:
 //   stage butterflies per tile 2112 / 1408 / 768 -> 2.75 / 1.83 / 1.0 rounds of 768 lanes.
 // ---------------------------------------------------------------------------------------
-#define FC_FAST_COL_CONFIGS(X) \
-    X(2112, 8, 12, 22, 8, 768)
+//   M = 1056 (FFT_H 2112, cfg5): 6 x 8 x 22, 16 columns per tile (full 128-byte lines), 768 threads
+//   M =  576 (transform 1152, cfg2): 6 x 8 x 12, 16 columns, 768 threads
+//   M =  144 (FFT_H 288, cfg1): 4 x 6 x 6, 16 columns, 384 threads
+#define FC_FAST_COL_CONFIGS(X)   \
+    X(2112, 8, 12, 22, 8, 768)   \
+    X(1056, 6, 8, 22, 16, 768)   \
+    X(576, 6, 8, 12, 16, 768)    \
+    X(144, 4, 6, 6, 16, 384)
 
 struct FastColsInfo {
     bool ok = false;
@@ -113,9 +146,11 @@ inline FastColsInfo fast_cols_lookup(int M) {
     return r;
 }
 
-// Paired-row kernel: same configurations as the single-row kernel.
+// Paired-row kernel: the one-row-per-workgroup configurations.
 template <class Runner>
-inline bool fast_rows_pair_dispatch(int L, int nz2_needed, Runner&& run) { return fast_rows_dispatch(L, nz2_needed, run); }
+inline bool fast_rows_pair_dispatch(int L, int nz2_needed, Runner&& run) { return fast_rows_rpw1_dispatch(L, nz2_needed, run); }
+
+inline bool fast_cols_length(int M) { return fast_cols_lookup(M).ok; }
 
 template <class Runner>
 inline bool fast_cols_dispatch(int M, Runner&& run) {

@@ -24,19 +24,21 @@
 
 namespace fc {
 
-template <int L_, int R1_, int R2_, int R3_, int NT_>
+// RPW rows of length L are transformed side by side by one workgroup of NT threads (short rows:
+// several per workgroup so that every stage still fills the lanes).
+template <int L_, int R1_, int R2_, int R3_, int NT_, int RPW_ = 1>
 struct RowCfg {
-    static constexpr int L = L_, R1 = R1_, R2 = R2_, R3 = R3_, NT = NT_;
+    static constexpr int L = L_, R1 = R1_, R2 = R2_, R3 = R3_, NT = NT_, RPW = RPW_;
     static constexpr int m1 = L / R1;        // stage-1 sub-length (= R2*R3)
-    static constexpr int NB1 = m1;           // butterflies per stage
+    static constexpr int NB1 = m1;           // butterflies per stage and row
     static constexpr int NB2 = R1 * R3;
     static constexpr int NB3 = R1 * R2;
-    static constexpr int RND1 = (NB1 + NT - 1) / NT;
-    static constexpr int RND2 = (NB2 + NT - 1) / NT;
+    static constexpr int RND1 = (RPW * NB1 + NT - 1) / NT;
+    static constexpr int RND2 = (RPW * NB2 + NT - 1) / NT;
     static constexpr int T2N = (R2 - 1) * R3;  // stage-2 twiddle entries
-    static constexpr int LDS_ELEMS = L + T2N;  // c32
+    static constexpr int LDS_ELEMS = RPW * L + T2N;  // c32
     static_assert(R1 * R2 * R3 == L, "radices must multiply to L");
-    static_assert(NB3 <= NT, "one stage-3 butterfly per thread");
+    static_assert(RPW * NB3 <= NT, "one stage-3 butterfly per thread");
     static_assert(R3 % 2 == 0, "register-order layout pairs stage-3 elements");
     static_assert((R3 * 8) % 16 == 0, "stage-3 runs must be 16-byte aligned");
 };
@@ -76,7 +78,7 @@ template <class C, bool MULTIF>
 struct RowState {
     c32 s[C::R3];                    // image spectrum of this thread's stage-3 butterfly
     c32 acc[MULTIF ? C::R3 : 1];     // feature accumulator (F > 1 only)
-    c32 x[(C::m1 + C::NT - 1) / C::NT > 4 ? 4 : (C::m1 + C::NT - 1) / C::NT];  // kernel row prefetch
+    c32 x[C::RND1];                  // kernel row prefetch: one value per stage-1 butterfly of this thread
 };
 
 // p[c] = w^c, c in [1, R)
@@ -95,39 +97,43 @@ struct alignas(16) c32x2 {
     c32 a, b;
 };
 
-// kw must satisfy kw <= min(m1, NZ2*R3, XR*NT) (checked by the launcher).
+// kw must satisfy kw <= min(m1, NZ2*R3) (checked at plan time / by the launcher).
 template <class C>
-constexpr int row_x_rounds() { return sizeof(RowState<C, false>::x) / sizeof(c32); }
+constexpr int row_x_rounds() { return C::RND1; }
 
 template <class C, int NZ2, bool MULTIF, class Ctx>
-FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, int kernel) {
-    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1;
-    constexpr int XR = row_x_rounds<C>();
+FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, int kernel, int rows) {
+    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
     using State = RowState<C, MULTIF>;
     const int nF = MULTIF ? g.F : 1;
-    c32* tw2 = lds + L;
+    c32* tw2 = lds + RPW * L;
     const int kw = g.kw;
+    const int row0 = group * RPW;   // this workgroup owns spectrum rows [row0, row0 + RPW) (those < rows)
 
-    // once per workgroup: stage-2 twiddles into LDS
+    // once per workgroup: stage-2 twiddles into LDS (first used in P2, after P1's barrier)
     ctx.phase_nosync([&](int t, State&) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
     });
 
     for (int f = 0; f < nF; f++) {
-        const c32* arow = g.A + (size_t)kernel * g.a_kernel_stride + (size_t)f * g.a_feat_stride + (size_t)row * g.a_pitch;
-        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)row * g.s_pitch;
+        const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride + (size_t)f * g.a_feat_stride;
+        const c32* sbase = g.S + (size_t)f * g.s_feat_stride;
 
-        // P0: issue the global loads of this (row, feature): kernel row and image spectrum
+        // P0: issue the global loads of this (row group, feature): kernel rows and image spectrum
         ctx.phase_nosync([&](int t, State& st) {
-            static_for<0, XR>([&](auto r_) {
+            static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                int j = t + NT * r;
-                st.x[r] = (j < kw) ? arow[j] : mk(0.f, 0.f);
+                const int u = t + NT * r;
+                const int rr = u / C::NB1, j = u - rr * C::NB1;
+                const int row = row0 + rr;
+                st.x[r] = (rr < RPW && row < rows && j < kw) ? abase[(size_t)row * g.a_pitch + j] : mk(0.f, 0.f);
             });
-            if (t < C::NB3) {
+            const int rr = t / C::NB3, q = t - rr * C::NB3;
+            if (rr < RPW && row0 + rr < rows) {
+                const c32* srow = sbase + (size_t)(row0 + rr) * g.s_pitch;
                 static_for<0, R3 / 2>([&](auto h_) {
                     constexpr int h = decltype(h_)::value;
-                    c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + t) * 2);
+                    c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
                     st.s[2 * h] = v.a;
                     st.s[2 * h + 1] = v.b;
                 });
@@ -137,16 +143,18 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
         // P1: forward stage 1, pruned: only input a = 0 of each butterfly is non-zero, so the
         // outputs are x[j] * w_L^{j c}
         ctx.phase([&](int t, State& st) {
-            static_for<0, XR>([&](auto r_) {
+            static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                int j = t + NT * r;
-                if (j < kw) {
+                const int u = t + NT * r;
+                const int rr = u / C::NB1, j = u - rr * C::NB1;
+                if (rr < RPW && j < kw) {
+                    c32* buf = lds + rr * L;
                     c32 p[R1];
                     power_chain<R1>(g.tw1[j], p);
-                    lds[j] = st.x[r];
+                    buf[j] = st.x[r];
                     static_for<1, R1>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;
-                        lds[c * m1 + j] = cmul(st.x[r], p[c]);
+                        buf[c * m1 + j] = cmul(st.x[r], p[c]);
                     });
                 }
             });
@@ -156,10 +164,11 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
         ctx.phase([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                int u = t + NT * r;
-                if (u < C::NB2) {
-                    int c1 = u / R3, b = u - c1 * R3;
-                    c32* p = lds + c1 * m1 + b;
+                const int u = t + NT * r;
+                const int rr = u / C::NB2, w = u - rr * C::NB2;
+                if (rr < RPW) {
+                    const int c1 = w / R3, b = w - c1 * R3;
+                    c32* p = lds + rr * L + c1 * m1 + b;
                     c32 v[R2];
                     static_for<0, R2>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
@@ -179,8 +188,9 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
         // P3: forward stage 3, product with the image spectrum, (feature sum,) inverse stage 3
         const bool last = (f == nF - 1);
         ctx.phase([&](int t, State& st) {
-            if (t < C::NB3) {
-                c32* p = lds + t * R3;
+            const int rr = t / C::NB3, q = t - rr * C::NB3;
+            if (rr < RPW) {
+                c32* p = lds + rr * L + q * R3;
                 c32 v[R3];
                 static_for<0, R3 / 2>([&](auto h_) {
                     constexpr int h = decltype(h_)::value;
@@ -220,10 +230,11 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
     ctx.phase([&](int t, State&) {
         static_for<0, C::RND2>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            int u = t + NT * r;
-            if (u < C::NB2) {
-                int c1 = u / R3, b = u - c1 * R3;
-                c32* p = lds + c1 * m1 + b;
+            const int u = t + NT * r;
+            const int rr = u / C::NB2, w = u - rr * C::NB2;
+            if (rr < RPW) {
+                const int c1 = w / R3, b = w - c1 * R3;
+                c32* p = lds + rr * L + c1 * m1 + b;
                 c32 v[R2];
                 v[0] = p[0];
                 static_for<1, R2>([&](auto c_) {
@@ -241,21 +252,25 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
 
     // P5: inverse stage 1 straight to global memory (natural w order, coalesced per a)
     const bool tiled = g.y_row_of != nullptr;
-    c32* yrow = g.Y + (size_t)kernel * g.y_kernel_stride + (tiled ? ((size_t)g.y_row_of[row] << g.y_tile_shift) : (size_t)row * g.y_pitch);
+    c32* ybase = g.Y + (size_t)kernel * g.y_kernel_stride;
     ctx.phase_nosync([&](int t, State&) {
         static_for<0, C::RND1>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            int j = t + NT * r;
-            if (j < C::NB1) {
+            const int u = t + NT * r;
+            const int rr = u / C::NB1, j = u - rr * C::NB1;
+            const int row = row0 + rr;
+            if (rr < RPW && row < rows) {
+                const c32* buf = lds + rr * L;
                 c32 p[R1];
                 power_chain<R1>(g.tw1[j], p);
                 c32 v[R1];
-                v[0] = lds[j];
+                v[0] = buf[j];
                 static_for<1, R1>([&](auto c_) {
                     constexpr int c = decltype(c_)::value;
-                    v[c] = cmulc(lds[c * m1 + j], p[c]);
+                    v[c] = cmulc(buf[c * m1 + j], p[c]);
                 });
                 Dft<R1, +1>::run(v);
+                c32* yrow = ybase + (tiled ? ((size_t)g.y_row_of[row] << g.y_tile_shift) : (size_t)row * g.y_pitch);
                 static_for<0, R1>([&](auto a_) {
                     constexpr int a = decltype(a_)::value;
                     int w = j + a * m1;
@@ -282,6 +297,7 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int row, in
 // ---------------------------------------------------------------------------------------
 template <class C, int NZ2, bool MULTIF, class Ctx>
 FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int rows, int item0, int item1) {
+    static_assert(C::RPW == 1, "the persistent variant handles one row per workgroup");
     constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1;
     constexpr int XR = row_x_rounds<C>();
     using State = RowState<C, MULTIF>;

@@ -47,6 +47,7 @@ struct RowPairState : RowState<C, MULTIF> {
 
 template <class C, int NZ2, bool MULTIF, class Ctx>
 FC_HD void fast_rows_pair_body(Ctx& ctx, c32* lds, const FastRowsPairArgs& ga, int pair_index, int kernel) {
+    static_assert(C::RPW == 1, "the paired variant is built on one-row-per-half configurations");
     constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1;
     constexpr int NTW = 2 * NT;
     constexpr int LB = L + 16;   // row B starts 32 banks away from row A: the A/B interleaved reads of P5 do not collide

@@ -70,9 +70,9 @@ struct DevPhaseCtx {
 };
 
 template <class Cfg, int NZ2, bool MULTIF>
-__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows(FastRowsArgs a) {
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows(FastRowsArgs a, int rows) {
     DevPhaseCtx<RowState<Cfg, MULTIF>> ctx;
-    fast_rows_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y);
+    fast_rows_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y, rows);
 }
 
 template <class Cfg, int NZ2, bool MULTIF>
@@ -161,8 +161,10 @@ struct FastColsLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg>
     void go() {
-        if (a.y_precombined) launch<Cfg, 2>();
-        else if (a.y_tiled) launch<Cfg, 1>();
+        if (a.y_precombined) {
+            if constexpr (Cfg::T == 8) launch<Cfg, 2>();   // precombined tiles are 8 columns wide
+            else err = hipErrorInvalidValue;
+        } else if (a.y_tiled) launch<Cfg, 1>();
         else launch<Cfg, 0>();
     }
     template <class Cfg, int PRE>
@@ -189,10 +191,12 @@ struct FastRowsLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg, int NZ2>
     void go() {
-        if (persist_wgs > 0) {
-            if (a.F > 1) launch_persist<Cfg, NZ2, true>();
-            else launch_persist<Cfg, NZ2, false>();
-            return;
+        if constexpr (Cfg::RPW == 1) {
+            if (persist_wgs > 0) {
+                if (a.F > 1) launch_persist<Cfg, NZ2, true>();
+                else launch_persist<Cfg, NZ2, false>();
+                return;
+            }
         }
         if (a.F > 1) launch<Cfg, NZ2, true>();
         else launch<Cfg, NZ2, false>();
@@ -222,7 +226,8 @@ struct FastRowsLauncher {
             if (err != hipSuccess) return;
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_fast_rows<Cfg, NZ2, MULTIF>), dim3(rows, kernels), dim3(Cfg::NT), lds, s, a);
+        const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
+        hipLaunchKernelGGL((k_fast_rows<Cfg, NZ2, MULTIF>), dim3(groups, kernels), dim3(Cfg::NT), lds, s, a, rows);
         err = hipGetLastError();
     }
 };

@@ -34,7 +34,7 @@ struct Geometry {
     FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
     FastColsInfo fast_cols;    // specialised output kernel, if one exists for M (needs the exact window)
     // precombined + tiled intermediate: both hot kernels fast, 8-column tiles (fast_rows_pair.hpp)
-    bool y_pre() const { return path_mode >= 3 && fast_rows.ok && fast_cols.ok && fast_cols.T == 8 && fft_w % 8 == 0 && wout == fft_w; }
+    bool y_pre() const { return path_mode >= 3 && fast_rows.ok && fast_rows.RPW == 1 && fast_cols.ok && fast_cols.T == 8 && exact_window; }
     // 0 generic kernels only; 1 fast kernels, row-major intermediate; 2 (default) + tiled
     // intermediate; 3 paired rows / precombined intermediate (measured slower on MI355X: the
     // 6-wave workgroups hide latency worse).  The other modes exist for tests and A/B runs.
@@ -65,6 +65,8 @@ struct Tables {
 inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw, int path_mode = 2) {
     const bool allow_fast = path_mode > 0;
     g.path_mode = path_mode;
+    fast_rows_hook() = allow_fast ? &fast_rows_length : nullptr;   // the planner prefers lengths with fast kernels
+    fast_cols_hook() = allow_fast ? &fast_cols_length : nullptr;
     if (const char* e = getenv("FFTCONV_TILE_W")) g.y_tile_w = (atoi(e) == 8) ? 8 : 16;        // A/B runs only
     if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e);
     if (const char* e = getenv("FFTCONV_ROWS_PERSIST")) g.rows_persistent = atoi(e) != 0;
@@ -92,7 +94,8 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     t.pairs = make_pair_table(t.pm);
     g.fast_rows = allow_fast ? fast_rows_lookup(g.Lw, max_kw) : FastRowsInfo();
     if (g.fast_rows.ok) t.fr = make_fast_rows_tables(g.fast_rows, t.pw);
-    g.fast_cols = (allow_fast && g.exact_window) ? fast_cols_lookup(g.M) : FastColsInfo();
+    // the fast output kernel crops (window <= transform) but does not zero-fill (window > transform)
+    g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M) : FastColsInfo();
     if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
     if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch, g.y_row_order);
     return true;

@@ -53,6 +53,7 @@ struct EmuFastRows {
     bool persist;
     template <class Cfg, int NZ2>
     void go() {
+        if constexpr (Cfg::RPW == 1)
         if (persist) {   // 5 persistent workgroups share the rows (uneven split on purpose)
             const int nwg = 5, total = rows;
             for (int wg = 0; wg < nwg; wg++) {
@@ -69,15 +70,15 @@ struct EmuFastRows {
             }
             return;
         }
-        for (int r = 0; r < rows; r++) {
+        for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
             // poison the LDS image so that reads of never-written cells show up
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
             if (a.F > 1) {
                 HostPhaseCtx<RowState<Cfg, true>> ctx(Cfg::NT);
-                fast_rows_body<Cfg, NZ2, true>(ctx, lds, a, r, 0);
+                fast_rows_body<Cfg, NZ2, true>(ctx, lds, a, grp, 0, rows);
             } else {
                 HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
-                fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, r, 0);
+                fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, grp, 0, rows);
             }
         }
     }
@@ -111,8 +112,9 @@ struct EmuFastCols {
         for (int wg = 0; wg < nwg; wg++) {
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
             HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
-            if (a.y_precombined) fast_cols_body<Cfg, 2>(ctx, lds, a, wg, nwg);
-            else if (a.y_tiled) fast_cols_body<Cfg, 1>(ctx, lds, a, wg, nwg);
+            if (a.y_precombined) {
+                if constexpr (Cfg::T == 8) fast_cols_body<Cfg, 2>(ctx, lds, a, wg, nwg);
+            } else if (a.y_tiled) fast_cols_body<Cfg, 1>(ctx, lds, a, wg, nwg);
             else fast_cols_body<Cfg, 0>(ctx, lds, a, wg, nwg);
         }
     }
@@ -265,7 +267,21 @@ int emu_uses_fast_rows(int H, int W, int F, int max_kh, int max_kw) {
     return (g.fast_rows.ok ? 1 : 0) | (g.fast_cols.ok ? 2 : 0);
 }
 
-int emu_choose_length(int need, int real_half, int exact) { return choose_length(need, real_half != 0, exact); }
+// the planner alone (no preference for lengths with specialised kernels)
+int emu_choose_length(int need, int real_half, int exact) {
+    fast_rows_hook() = nullptr;
+    fast_cols_hook() = nullptr;
+    return choose_length(need, real_half != 0, exact);
+}
+// transform lengths a plan of these sizes would use (path mode as set by emu_allow_fast)
+int emu_plan_lengths(int H, int W, int F, int max_kh, int max_kw, int* lh, int* lw) {
+    Geometry g;
+    Tables t;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    *lh = g.Lh;
+    *lw = g.Lw;
+    return 0;
+}
 int emu_length_supported(int L) { return length_supported(L) ? 1 : 0; }
 
 }  // extern "C"

@@ -16,6 +16,11 @@ EMU_DIR = os.path.join(util.ROOT, "tests", "emu")
 ROW_SHAPES = [(20, 4096, 1, 5, 127, 2), (20, 4100, 2, 5, 120, 1), (12, 4000, 1, 3, 200, 1), (12, 3700, 3, 3, 500, 1)]
 COL_SHAPES = [(4200, 10, 2, 25, 7, 1), (4096, 24, 1, 127, 9, 2)]
 BOTH_SHAPE = (4096, 4096, 1, 127, 127, 1)
+# the other specialised configurations: cfg1 (288), cfg2 (1088 window on a 1152 transform),
+# cfg5 (2112), cfg4's 4160 window cropped from the 4224 transform, plus multi-feature / ragged
+OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 2048, 1, 63, 63, 1),
+                (4096, 300, 1, 63, 20, 1), (300, 4096, 2, 20, 63, 1), (1000, 1000, 3, 40, 50, 2),
+                (2000, 260, 1, 100, 29, 1), (250, 280, 2, 9, 9, 2)]
 VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent)
     (0, 16, 0, 0), (1, 16, 0, 0), (1, 16, 0, 1), (2, 16, 0, 0), (2, 8, 0, 0), (2, 8, 1, 0), (2, 8, 2, 1), (2, 16, 2, 1), (3, 8, 0, 0)]
 
@@ -82,6 +87,21 @@ def test_emulated_fast_kernels_all_variants(emu, oracle, monkeypatch, variant):
     assert util.rel_err(got[0], oracle.conv_fft(data, kh, kw, ks)[0]) < 1e-5
 
 
+@pytest.mark.parametrize("shape", OTHER_SHAPES)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_emulated_fast_kernels_other_configs(emu, oracle, monkeypatch, shape, mode):
+    set_variant(monkeypatch, (mode, 16, 0, 0))
+    emu.emu_allow_fast(mode)
+    H, W, F, kh, kw, n = shape
+    assert emu.emu_uses_fast_rows(H, W, F, kh, kw) > 0
+    data, ks = make_inputs(shape, 29)
+    rc, got = emu_conv(emu, data, kh, kw, ks)
+    emu.emu_allow_fast(2)
+    assert rc == 0
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
 def test_fast_row_kernel_rejects_too_wide_kernels(emu, monkeypatch):
     # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224); plans for
     # wider MAX_KERNEL_W fall back to the generic kernel at plan time
@@ -107,6 +127,18 @@ def test_gpu_fast_kernels_one_dimension(fftconv, oracle, monkeypatch, shape, mod
     set_variant(monkeypatch, (mode, 16, 0, 0))
     H, W, F, kh, kw, n = shape
     data, ks = make_inputs(shape, 23)
+    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", OTHER_SHAPES)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gpu_fast_kernels_other_configs(fftconv, oracle, monkeypatch, shape, mode):
+    set_variant(monkeypatch, (mode, 16, 0, 0))
+    H, W, F, kh, kw, n = shape
+    data, ks = make_inputs(shape, 31)
     got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < 1e-5

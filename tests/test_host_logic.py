@@ -74,11 +74,26 @@ def test_choose_length(emu, need, exact):
 
 
 def test_baseline_configs_use_the_reference_window(emu):
-    # every BASELINE config's ceil16 window factors into the engine's radices, so the internal
-    # transform equals the reference's circular modulus
+    # every BASELINE config's ceil16 window factors into the engine's radices, so with the generic
+    # kernels the internal transform equals the reference's circular modulus
     for need, win in [(286, 288), (1086, 1088), (4222, 4224), (4158, 4160), (2110, 2112)]:
         assert emu.emu_choose_length(need, 1, win) == win
         assert emu.emu_choose_length(need, 0, win) == win
+
+
+def test_plans_prefer_lengths_with_specialised_kernels(emu):
+    """cfg1/3/5 run at their window; cfg2 (1088) and cfg4 (4160) move to 1152 / 4224 where
+    specialised kernels exist; path mode 0 (generic kernels only) stays at the window"""
+    lh, lw = ctypes.c_int(), ctypes.c_int()
+    want = {(256, 31): 288, (1024, 63): 1152, (4096, 127): 4224, (4096, 63): 4224, (2048, 63): 2112}
+    for (n, k), L in want.items():
+        emu.emu_allow_fast(2)
+        assert emu.emu_plan_lengths(n, n, 1, k, k, ctypes.byref(lh), ctypes.byref(lw)) == 0
+        assert (lh.value, lw.value) == (L, L)
+        emu.emu_allow_fast(0)
+        assert emu.emu_plan_lengths(n, n, 1, k, k, ctypes.byref(lh), ctypes.byref(lw)) == 0
+        assert (lh.value, lw.value) == (util.ceil16(n + k - 1),) * 2
+    emu.emu_allow_fast(2)
 
 
 @pytest.mark.parametrize("case", golden_util.golden_cases())
