@@ -38,9 +38,14 @@ struct ColCfg {
     // LDS image (c32 units): columns | stage-2 twiddles | stage-1 base twiddles | pair table
     static constexpr int OFF_T2 = T * LP;
     static constexpr int OFF_T1 = OFF_T2 + T2N;
-    static constexpr int OFF_PAIR = OFF_T1 + m1 + ((OFF_T1 + m1) & 1);  // 16-byte aligned
+    // pair table, compact: positions packed as a | b << 16 (one dword per pair), the twiddle
+    // w_N^k rebuilt as WH[k >> 5] * WL[k & 31] from two tiny tables
     static constexpr int NPE = M / 2 + 1;                                 // pair entries (incl. DC, middle)
-    static constexpr int LDS_ELEMS = OFF_PAIR + 2 * NPE;                  // PairEntry = 2 c32
+    static constexpr int NWH = (NPE + 31) / 32;
+    static constexpr int OFF_WH = OFF_T1 + m1;
+    static constexpr int OFF_WL = OFF_WH + NWH;
+    static constexpr int OFF_PAIR = OFF_WL + 32;                          // NPE dwords = (NPE + 1) / 2 c32
+    static constexpr int LDS_ELEMS = OFF_PAIR + (NPE + 1) / 2;
     static_assert(R1 * R2 * R3 == M, "radices must multiply to M");
     static_assert(M % 2 == 0 && T % 2 == 0, "even M and T");
     static_assert(NB3 * T == NT, "one stage-3 butterfly per thread");
@@ -69,7 +74,7 @@ struct FastColsArgs {
     const int* rowoff;       // M+1 entries: Y row offset (row * y_pitch) feeding LDS position p
     const c32* tw1;          // w_M^j, j < m1
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
-    const PairEntry* pairs;  // NPE entries: [0] DC/Nyquist, [k] pair (k, M-k), [M/2] middle
+    const PairEntry* pairs;  // NPE entries: [0] DC/Nyquist, [k] pair (k, M-k), [M/2] middle (w = w_N^k)
 };
 
 template <class C>
@@ -91,7 +96,9 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     using State = ColState<C>;
     c32* tw2 = lds + C::OFF_T2;
     c32* tw1 = lds + C::OFF_T1;
-    PairEntry* pairs = reinterpret_cast<PairEntry*>(lds + C::OFF_PAIR);
+    c32* wh = lds + C::OFF_WH;
+    c32* wl = lds + C::OFF_WL;
+    unsigned* ppos = reinterpret_cast<unsigned*>(lds + C::OFF_PAIR);
 
     // Tile order.  Adjacent column tiles share every 128-byte line of Y (a tile row is 64 bytes),
     // so they should be gathered at the same time through the same L2: workgroups b and b+8 sit
@@ -160,7 +167,12 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
         for (int i = t; i < m1; i += NT) tw1[i] = g.tw1[i];
         if constexpr (!PRE)
-            for (int i = t; i < C::NPE; i += NT) pairs[i] = g.pairs[i];
+            for (int i = t; i < C::NPE; i += NT) {
+                const PairEntry e = g.pairs[i];
+                ppos[i] = (unsigned)e.a | ((unsigned)e.b << 16);
+                if ((i & 31) == 0) wh[i >> 5] = e.w;      // w^(32*hi)
+                if (i < 32) wl[i] = e.w;                  // w^lo  (entry 0 holds w^0 = 1)
+            }
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             st.off[r] = (PRE || TILED) ? g.lpos[(t + NT * r) / T2] : g.rowoff[(t + NT * r) / T2];
@@ -192,25 +204,28 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 if (idx < C::NPAIR * T) {
                     const int k = idx / T + 1, col = idx % T;
                     c32* z = lds + col * LP;
-                    const PairEntry e = pairs[k];
-                    c32 xk = z[e.a], xm = z[e.b];
+                    const unsigned pp = ppos[k];
+                    const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
+                    const c32 w = cmul(wh[k >> 5], wl[k & 31]);
+                    c32 xk = z[pa], xm = z[pb];
                     c32 Ssum = mk(xk.x + xm.x, xk.y - xm.y);
                     c32 D = mk(xk.x - xm.x, xk.y + xm.y);
-                    c32 G = cmulc(D, e.w);
-                    z[e.a] = mk(Ssum.x - G.y, Ssum.y + G.x);
-                    z[e.b] = mk(Ssum.x + G.y, -Ssum.y + G.x);
+                    c32 G = cmulc(D, w);
+                    z[pa] = mk(Ssum.x - G.y, Ssum.y + G.x);
+                    z[pb] = mk(Ssum.x + G.y, -Ssum.y + G.x);
                 }
             }
             if (t < T) {  // DC / Nyquist
                 c32* z = lds + t * LP;
-                const PairEntry e = pairs[0];
-                float x0 = z[e.a].x, xm = z[e.b].x;
-                z[e.a] = mk(x0 + xm, x0 - xm);
+                const unsigned pp = ppos[0];
+                const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
+                float x0 = z[pa].x, xm = z[pb].x;
+                z[pa] = mk(x0 + xm, x0 - xm);
             } else if (t < 2 * T) {  // middle bin
                 c32* z = lds + (t - T) * LP;
-                const PairEntry e = pairs[M / 2];
-                c32 x = z[e.a];
-                z[e.a] = mk(2.f * x.x, -2.f * x.y);
+                const int pa = (int)(ppos[M / 2] & 0xffffu);
+                c32 x = z[pa];
+                z[pa] = mk(2.f * x.x, -2.f * x.y);
             }
         });
 

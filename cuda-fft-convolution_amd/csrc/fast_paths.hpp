@@ -121,8 +121,11 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   M = 1056 (FFT_H 2112, cfg5): 6 x 8 x 22, 16 columns per tile (full 128-byte lines), 768 threads
 //   M =  576 (transform 1152, cfg2): 6 x 8 x 12, 16 columns, 768 threads
 //   M =  144 (FFT_H 288, cfg1): 4 x 6 x 6, 16 columns, 384 threads
+//   M = 2112 also as 4 columns / 384 threads (two workgroups per CU): measured much slower
+//   (32-byte gather pieces: 47.8 vs 36.1 us per map); kept for A/B via FFTCONV_COLS_T=4.
 #define FC_FAST_COL_CONFIGS(X)   \
     X(2112, 8, 12, 22, 8, 768)   \
+    X(2112, 8, 12, 22, 4, 384)   \
     X(1056, 6, 8, 22, 16, 768)   \
     X(576, 6, 8, 12, 16, 768)    \
     X(144, 4, 6, 6, 16, 384)
@@ -133,10 +136,11 @@ struct FastColsInfo {
     size_t lds_bytes = 0;
 };
 
-inline FastColsInfo fast_cols_lookup(int M) {
+// prefer_T > 0: only the configuration with that tile width
+inline FastColsInfo fast_cols_lookup(int M, int prefer_T = 0) {
     FastColsInfo r;
 #define FC_X(MM, A, B, C, TT, NTT)                                                   \
-    if (!r.ok && M == MM) {                                                          \
+    if (!r.ok && M == MM && (prefer_T <= 0 || prefer_T == TT)) {                     \
         using Cfg = ColCfg<MM, A, B, C, TT, NTT>;                                    \
         r.ok = true; r.M = MM; r.R1 = A; r.R2 = B; r.R3 = C; r.T = TT; r.NT = NTT;   \
         r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);                          \
@@ -153,9 +157,9 @@ inline bool fast_rows_pair_dispatch(int L, int nz2_needed, Runner&& run) { retur
 inline bool fast_cols_length(int M) { return fast_cols_lookup(M).ok; }
 
 template <class Runner>
-inline bool fast_cols_dispatch(int M, Runner&& run) {
+inline bool fast_cols_dispatch(int M, int T, Runner&& run) {
 #define FC_X(MM, A, B, C, TT, NTT)                          \
-    if (M == MM) {                                          \
+    if (M == MM && T == TT) {                               \
         run.template go<ColCfg<MM, A, B, C, TT, NTT>>();    \
         return true;                                        \
     }

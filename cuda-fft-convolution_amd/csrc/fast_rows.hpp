@@ -22,6 +22,10 @@
 #include "butterflies.hpp"
 #include "fc_common.hpp"
 
+#ifndef FC_ROWS1_DBG
+#define FC_ROWS1_DBG 0   // timing experiments only (wrong results): 1 no stores, 2 no S loads, 4 no final phase
+#endif
+
 namespace fc {
 
 // RPW rows of length L are transformed side by side by one workgroup of NT threads (short rows:
@@ -129,7 +133,7 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, 
                 st.x[r] = (rr < RPW && row < rows && j < kw) ? abase[(size_t)row * g.a_pitch + j] : mk(0.f, 0.f);
             });
             const int rr = t / C::NB3, q = t - rr * C::NB3;
-            if (rr < RPW && row0 + rr < rows) {
+            if ((FC_ROWS1_DBG & 2) == 0 && rr < RPW && row0 + rr < rows) {
                 const c32* srow = sbase + (size_t)(row0 + rr) * g.s_pitch;
                 static_for<0, R3 / 2>([&](auto h_) {
                     constexpr int h = decltype(h_)::value;
@@ -251,6 +255,7 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, 
     });
 
     // P5: inverse stage 1 straight to global memory (natural w order, coalesced per a)
+    if constexpr (FC_ROWS1_DBG & 4) return;
     const bool tiled = g.y_row_of != nullptr;
     c32* ybase = g.Y + (size_t)kernel * g.y_kernel_stride;
     ctx.phase_nosync([&](int t, State&) {
@@ -274,7 +279,7 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, 
                 static_for<0, R1>([&](auto a_) {
                     constexpr int a = decltype(a_)::value;
                     int w = j + a * m1;
-                    if (w < g.wout) {
+                    if ((FC_ROWS1_DBG & 1) ? (v[a].x == 1.2345e-30f) : (w < g.wout)) {
                         if (tiled) yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))] = v[a];
                         else yrow[w] = v[a];
                     }

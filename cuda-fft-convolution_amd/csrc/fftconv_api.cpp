@@ -229,7 +229,7 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
                 HIP_TRY(launch_fast_rows_pair(g.Lw, fast_rows_nz2(g, kw), fa, g.M / 2 + 1, ny, p->stream));
             } else if (g.fast_rows.ok) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
-                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_persistent ? 4 * p->num_cus : 0, p->stream));
+                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_persistent ? 4 * p->num_cus : 0, g.rows_wg_order, p->stream));
             } else {
                 SpectralRowsArgs sa = spectral_rows_args(g, p->t, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
@@ -239,7 +239,7 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
             if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
             if (g.fast_cols.ok) {
                 FastColsArgs fa = fast_cols_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
-                HIP_TRY(launch_fast_cols(g.M, fa, p->num_cus, p->stream));
+                HIP_TRY(launch_fast_cols(g.M, g.fast_cols.T, fa, p->num_cus, p->stream));
             } else {
                 ColsC2RArgs ca = cols_c2r_args(g, p->t, p->d, p->Y.p, obase, g.map_elems());
                 HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));

@@ -69,10 +69,31 @@ struct DevPhaseCtx {
     }
 };
 
+// Workgroup -> (row group, kernel).  order 0: blockIdx = (group, kernel).  order 1: 1-D grid with
+// the kernel index fastest: the workgroups that multiply by the same image-spectrum rows run back
+// to back.  order 2: additionally XCD-aware -- blocks b and b+8 share an XCD (round-robin
+// dispatch; a speed assumption only), so XCD x = b % 8 walks groups x, x+8, ... with the kernel
+// index fastest and every spectrum row is fetched once per XCD L2 instead of once per kernel.
 template <class Cfg, int NZ2, bool MULTIF>
-__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows(FastRowsArgs a, int rows) {
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows(FastRowsArgs a, int rows, int order, int groups, int nk) {
+    int group, kernel;
+    if (order == 0) {
+        group = (int)blockIdx.x;
+        kernel = (int)blockIdx.y;
+    } else if (order == 1) {
+        const int b = (int)blockIdx.x;
+        group = b / nk;
+        kernel = b - group * nk;
+    } else {
+        const int b = (int)blockIdx.x;
+        const int xcd = b & 7, sq = b >> 3;
+        const int gl = sq / nk;
+        kernel = sq - gl * nk;
+        group = gl * 8 + xcd;
+        if (group >= groups) return;
+    }
     DevPhaseCtx<RowState<Cfg, MULTIF>> ctx;
-    fast_rows_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y, rows);
+    fast_rows_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, group, kernel, rows);
 }
 
 template <class Cfg, int NZ2, bool MULTIF>
@@ -92,7 +113,7 @@ __global__ void __launch_bounds__(256) k_relayout_rows(RelayoutArgs a) {
 }
 
 template <class Cfg, int MODE>
-__global__ void __launch_bounds__(Cfg::NT, Cfg::NT / 256) k_fast_cols(FastColsArgs a) {
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols(FastColsArgs a) {
     DevPhaseCtx<ColState<Cfg>> ctx;
     fast_cols_body<Cfg, MODE>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
 }
@@ -177,7 +198,10 @@ struct FastColsLauncher {
             if (err != hipSuccess) return;
             attr_set = true;
         }
-        const int grid = a.ntiles < max_wg ? a.ntiles : max_wg;
+        // persistent: as many workgroups as fit at once (LDS-limited), one or two per CU
+        const int per_cu = (int)((size_t)(160 * 1024) / lds) < 768 / Cfg::NT ? (int)((size_t)(160 * 1024) / lds) : 768 / Cfg::NT;
+        const int want = max_wg * (per_cu < 1 ? 1 : per_cu);
+        const int grid = a.ntiles < want ? a.ntiles : want;
         hipLaunchKernelGGL((k_fast_cols<Cfg, PRE>), dim3(grid), dim3(Cfg::NT), lds, s, a);
         err = hipGetLastError();
     }
@@ -188,6 +212,7 @@ struct FastRowsLauncher {
     int rows, kernels;
     hipStream_t s;
     int persist_wgs = 0;   // > 0: persistent variant with that many workgroups
+    int order = 0;         // workgroup order of the plain variant (see k_fast_rows)
     hipError_t err = hipSuccess;
     template <class Cfg, int NZ2>
     void go() {
@@ -227,16 +252,19 @@ struct FastRowsLauncher {
             attr_set = true;
         }
         const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
-        hipLaunchKernelGGL((k_fast_rows<Cfg, NZ2, MULTIF>), dim3(groups, kernels), dim3(Cfg::NT), lds, s, a, rows);
+        dim3 grid(groups, kernels);
+        if (order == 1) grid = dim3(groups * kernels);
+        if (order == 2) grid = dim3(8 * ((groups + 7) / 8) * kernels);
+        hipLaunchKernelGGL((k_fast_rows<Cfg, NZ2, MULTIF>), grid, dim3(Cfg::NT), lds, s, a, rows, order, groups, kernels);
         err = hipGetLastError();
     }
 };
 
 }  // namespace
 
-hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, hipStream_t s) {
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, int order, hipStream_t s) {
     if (rows <= 0 || kernels <= 0) return hipSuccess;
-    FastRowsLauncher l{a, rows, kernels, s, persist_wgs};
+    FastRowsLauncher l{a, rows, kernels, s, persist_wgs, order};
     if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
     return l.err;
 }
@@ -248,10 +276,10 @@ hipError_t launch_fast_rows_pair(int L, int nz2, const FastRowsPairArgs& a, int 
     return l.err;
 }
 
-hipError_t launch_fast_cols(int M, const FastColsArgs& a, int max_workgroups, hipStream_t s) {
+hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
-    FastColsLauncher l{a, max_workgroups, s};
-    if (!fast_cols_dispatch(M, l)) return hipErrorInvalidValue;
+    FastColsLauncher l{a, num_cus, s};
+    if (!fast_cols_dispatch(M, T, l)) return hipErrorInvalidValue;
     return l.err;
 }
 

@@ -15,9 +15,9 @@ hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t l
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 // fast path (fast_rows.hpp); hipErrorInvalidValue if no instantiation matches (L, nz2)
 // persist_wgs > 0: persistent variant (workgroups walk contiguous runs of (kernel, row) items)
-hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, hipStream_t s);
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, int order, hipStream_t s);
 hipError_t launch_fast_rows_pair(int L, int nz2, const FastRowsPairArgs& a, int pairs, int kernels, hipStream_t s);
-hipError_t launch_fast_cols(int M, const FastColsArgs& a, int max_workgroups, hipStream_t s);
+hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_relayout_rows(const RelayoutArgs& a, int rows, hipStream_t s);
 hipError_t launch_cols_c2r(const ColsC2RArgs& a, int tiles, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 

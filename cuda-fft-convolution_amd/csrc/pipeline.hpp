@@ -44,6 +44,7 @@ struct Geometry {
     int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
     int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
     int y_row_order = 0;       // see make_fast_cols_tables
+    int rows_wg_order = 0;     // workgroup order of the fast row kernel (kernels.hip: k_fast_rows); 1, 2 measured equal
     bool rows_persistent = false; // persistent variant of the fast single-row kernel (measured slower: kept for A/B)
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
@@ -70,6 +71,7 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (const char* e = getenv("FFTCONV_TILE_W")) g.y_tile_w = (atoi(e) == 8) ? 8 : 16;        // A/B runs only
     if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e);
     if (const char* e = getenv("FFTCONV_ROWS_PERSIST")) g.rows_persistent = atoi(e) != 0;
+    if (const char* e = getenv("FFTCONV_ROWS_ORDER")) g.rows_wg_order = atoi(e);
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
     g.fft_h = fft_size16(H + max_kh - 1);
@@ -95,7 +97,9 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     g.fast_rows = allow_fast ? fast_rows_lookup(g.Lw, max_kw) : FastRowsInfo();
     if (g.fast_rows.ok) t.fr = make_fast_rows_tables(g.fast_rows, t.pw);
     // the fast output kernel crops (window <= transform) but does not zero-fill (window > transform)
-    g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M) : FastColsInfo();
+    int prefer_T = 0;
+    if (const char* e = getenv("FFTCONV_COLS_T")) prefer_T = atoi(e);                          // A/B runs only
+    g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M, prefer_T) : FastColsInfo();
     if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
     if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch, g.y_row_order);
     return true;

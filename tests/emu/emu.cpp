@@ -215,7 +215,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fc_rowoff = t.fcl.rowoff.data();
             FastColsArgs fa = fast_cols_args(g, d, Y.data(), out[k], 0, 1);
             EmuFastCols run{fa, lds.data(), 3};   // 3 persistent workgroups share the tiles
-            if (!fast_cols_dispatch(g.M, run)) return -6;
+            if (!fast_cols_dispatch(g.M, g.fast_cols.T, run)) return -6;
         } else {
             ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
             for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
