@@ -18,7 +18,7 @@
 #include "fc_common.hpp"
 
 #ifndef FC_COLS_DBG
-#define FC_COLS_DBG 0   // timing experiments only (wrong results): 1 skip pair pass, 2 no barriers between stages, 4 no gather loads, 8 no stores
+#define FC_COLS_DBG 0   // timing experiments only (wrong results): 1 skip pair pass, 2 no barriers between stages, 4 no gather loads, 8 no stores, 16 contiguous gather addresses (tiled mode)
 #endif
 
 namespace fc {
@@ -133,7 +133,9 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             static_for<0, C::UPT>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int e = t + NT * r;
-                if constexpr (!(FC_COLS_DBG & 4))
+                if constexpr ((FC_COLS_DBG & 16) != 0)   // timing experiment: contiguous half-tile
+                    st.pre[r] = *reinterpret_cast<const c32x2*>(Yt - (w0 & (tw - 1)) + (size_t)((w0 & (tw - 1)) / T) * (M * T) + 2 * e);
+                else if constexpr (!(FC_COLS_DBG & 4))
                     st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + ((e / T2) << g.y_tile_shift) + 2 * (e % T2));
             });
             if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Yt + (M << g.y_tile_shift) + 2 * t);

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fast_cols.hpp"
+#include "fast_cols_wide.hpp"
 #include "fast_rows.hpp"
 #include "fast_rows_pair.hpp"
 #include "planner.hpp"
@@ -243,6 +244,87 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
         t.row_pairs.push_back(rp);
         t.lpos[rp.outA] = t.plan.pos[M / 2];
     }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// 16-column output kernel (fast_cols_wide.hpp): X(H, R2, R3, R4, NT), transform M = 2H.
+//   M = 2112 = 2 x (6 x 8 x 22): the cfg3 / cfg4 output pass.
+// ---------------------------------------------------------------------------------------
+#define FC_FAST_COLW_CONFIGS(X) \
+    X(1056, 6, 8, 22, 768)
+
+struct FastColsWideInfo {
+    bool ok = false;
+    int H = 0, R2 = 0, R3 = 0, R4 = 0, NT = 0;
+    size_t lds_bytes = 0;
+};
+
+inline FastColsWideInfo fast_cols_wide_lookup(int M) {
+    FastColsWideInfo r;
+#define FC_X(HH, A, B, C, NTT)                                              \
+    if (!r.ok && M == 2 * HH) {                                             \
+        using Cfg = ColWideCfg<HH, A, B, C, NTT>;                           \
+        r.ok = true; r.H = HH; r.R2 = A; r.R3 = B; r.R4 = C; r.NT = NTT;    \
+        r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);                 \
+    }
+    FC_FAST_COLW_CONFIGS(FC_X)
+#undef FC_X
+    return r;
+}
+
+template <class Runner>
+inline bool fast_cols_wide_dispatch(int M, Runner&& run) {
+#define FC_X(HH, A, B, C, NTT)                               \
+    if (M == 2 * HH) {                                       \
+        run.template go<ColWideCfg<HH, A, B, C, NTT>>();     \
+        return true;                                         \
+    }
+    FC_FAST_COLW_CONFIGS(FC_X)
+#undef FC_X
+    return false;
+}
+
+struct FastColsWideTables {
+    Plan1D plan;                        // radices (2, R2, R3, R4)
+    std::vector<c32> tw3, twA, twF, wh, wl;
+    std::vector<unsigned> ppA, ppB;
+    std::vector<int> tile_row_of;       // M+1: generic spectrum row i -> row of the 16-column tile
+};
+
+inline FastColsWideTables make_fast_cols_wide_tables(const FastColsWideInfo& fi, const Plan1D& generic) {
+    FastColsWideTables t;
+    const int H = fi.H, M = 2 * H, m2 = H / fi.R2;
+    t.plan = make_plan1d_seq(M, {2, fi.R2, fi.R3, fi.R4});
+    const StageDesc& s1 = t.plan.desc.st[0];   // radix 2, m = H:   w_M^b
+    const StageDesc& s2 = t.plan.desc.st[1];   // radix R2, m = m2: w_H^(b c)
+    const StageDesc& s3 = t.plan.desc.st[2];   // radix R3, m = R4
+    t.twF.assign(t.plan.tw.begin() + s1.tw_off, t.plan.tw.begin() + s1.tw_off + m2);
+    t.twA.assign(t.plan.tw.begin() + s2.tw_off, t.plan.tw.begin() + s2.tw_off + m2);
+    t.tw3.assign(t.plan.tw.begin() + s3.tw_off, t.plan.tw.begin() + s3.tw_off + (fi.R3 - 1) * fi.R4);
+    const int N = 2 * M;
+    for (int i = 0; i < M / 32 + 2; i++) {
+        double a = -2.0 * M_PI * (double)(32 * i) / (double)N;
+        t.wh.push_back(mk((float)std::cos(a), (float)std::sin(a)));
+    }
+    for (int i = 0; i < 32; i++) {
+        double a = -2.0 * M_PI * (double)i / (double)N;
+        t.wl.push_back(mk((float)std::cos(a), (float)std::sin(a)));
+    }
+    const std::vector<int>& pos = t.plan.pos;   // even bins in [0, H), odd bins in [H, 2H)
+    for (int i = 0; i <= H / 2; i++) {          // half A: k = 2i
+        const int k = 2 * i;
+        unsigned a = (unsigned)pos[k], b = (i == 0) ? (unsigned)H : (unsigned)pos[M - k];
+        t.ppA.push_back(a | (b << 16));
+    }
+    for (int i = 0; i < H / 2; i++) {           // half B: k = 2i + 1
+        const int k = 2 * i + 1;
+        unsigned a = (unsigned)(pos[k] - H), b = (unsigned)(pos[M - k] - H);
+        t.ppB.push_back(a | (b << 16));
+    }
+    t.tile_row_of.assign(M + 1, 0);
+    for (int k = 0; k < M; k++) t.tile_row_of[generic.pos[k]] = (k & 1) ? pos[k] + 1 : pos[k];
+    t.tile_row_of[M] = H;
     return t;
 }
 

@@ -24,6 +24,14 @@
 #define FC_NOUNROLL
 #endif
 
+// Scheduling fence (device only): keeps the compiler from interleaving the unrolled rounds of a
+// phase, which multiplies their register footprint.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FC_SCHED_FENCE() ((void)0)
+#endif
+
 namespace fc {
 
 struct alignas(8) c32 {

@@ -111,6 +111,9 @@ struct fftconv_plan {
     DevBuf<PairEntry> fc_pairs;
     DevBuf<int> fc_rowoff, fc_tile_row_of, fc_lpos, fc_tile_lpos;
     DevBuf<RowPair> fc_row_pairs;
+    DevBuf<c32> cw_tw3, cw_twA, cw_twF, cw_wh, cw_wl;
+    DevBuf<unsigned> cw_ppA, cw_ppB;
+    DevBuf<int> cw_tile_row_of;
     int num_cus = 256;
     long opt_batch_maps = 0;
     bool profile = false;
@@ -166,6 +169,8 @@ struct fftconv_plan {
         S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
         S0.release(); fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release();
+        cw_tw3.release(); cw_twA.release(); cw_twF.release(); cw_wh.release(); cw_wl.release();
+        cw_ppA.release(); cw_ppB.release(); cw_tile_row_of.release();
     }
 };
 
@@ -237,7 +242,10 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
             if (int rc = p->prof_end()) return rc;
             float* obase = staged ? p->O.p : sink.packed + (size_t)(a0 + y0) * g.map_elems();
             if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
-            if (g.fast_cols.ok) {
+            if (g.use_wide()) {
+                FastColsWideArgs fa = fast_cols_wide_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
+                HIP_TRY(launch_fast_cols_wide(g.M, fa, p->num_cus, p->stream));
+            } else if (g.fast_cols.ok) {
                 FastColsArgs fa = fast_cols_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
                 HIP_TRY(launch_fast_cols(g.M, g.fast_cols.T, fa, p->num_cus, p->stream));
             } else {
@@ -360,6 +368,25 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
             if ((rc = cp(p->fc_tile_lpos.p, ft.tile_lpos.data(), ft.tile_lpos.size() * sizeof(int)))) break;
             p->d.fc_tile_lpos = p->fc_tile_lpos.p;
             p->d.fc_row_pairs = p->fc_row_pairs.p;
+        }
+        if (p->g.fast_colw.ok) {
+            const FastColsWideTables& fw = p->t.fcw;
+            auto up = [&](auto& buf, const auto& vec) -> int {
+                if (int r = buf.ensure(vec.size())) return r;
+                return cp(buf.p, vec.data(), vec.size() * sizeof(vec[0]));
+            };
+            if ((rc = up(p->cw_tw3, fw.tw3))) break;
+            if ((rc = up(p->cw_twA, fw.twA))) break;
+            if ((rc = up(p->cw_twF, fw.twF))) break;
+            if ((rc = up(p->cw_wh, fw.wh))) break;
+            if ((rc = up(p->cw_wl, fw.wl))) break;
+            if ((rc = up(p->cw_ppA, fw.ppA))) break;
+            if ((rc = up(p->cw_ppB, fw.ppB))) break;
+            if ((rc = up(p->cw_tile_row_of, fw.tile_row_of))) break;
+            p->d.cw_tw3 = p->cw_tw3.p; p->d.cw_twA = p->cw_twA.p; p->d.cw_twF = p->cw_twF.p;
+            p->d.cw_wh = p->cw_wh.p; p->d.cw_wl = p->cw_wl.p;
+            p->d.cw_ppA = p->cw_ppA.p; p->d.cw_ppB = p->cw_ppB.p;
+            p->d.cw_tile_row_of = p->cw_tile_row_of.p;
         }
         if (p->g.fast_rows.ok) {
             const FastRowsTables& fr = p->t.fr;

@@ -142,6 +142,33 @@ __global__ void __launch_bounds__(2 * Cfg::NT, 3) k_fast_rows_pair(FastRowsPairA
 #define FC_PAIR_XCD_REMAP 0
 #endif
 
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols_wide(FastColsWideArgs a) {
+    DevPhaseCtx<ColWideState<Cfg>> ctx;
+    fast_cols_wide_body<Cfg>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+struct FastColsWideLauncher {
+    const FastColsWideArgs& a;
+    int num_cus;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg>
+    void go() {
+        static bool attr_set = false;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        if (!attr_set) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cols_wide<Cfg>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (err != hipSuccess) return;
+            attr_set = true;
+        }
+        const int grid = a.ntiles < num_cus ? a.ntiles : num_cus;   // persistent, one workgroup per CU
+        hipLaunchKernelGGL((k_fast_cols_wide<Cfg>), dim3(grid), dim3(Cfg::NT), lds, s, a);
+        err = hipGetLastError();
+    }
+};
+
 struct FastRowsPairLauncher {
     const FastRowsPairArgs& a;
     int pairs, kernels;
@@ -280,6 +307,13 @@ hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hi
     if (a.ntiles <= 0) return hipSuccess;
     FastColsLauncher l{a, num_cus, s};
     if (!fast_cols_dispatch(M, T, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+hipError_t launch_fast_cols_wide(int M, const FastColsWideArgs& a, int num_cus, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    FastColsWideLauncher l{a, num_cus, s};
+    if (!fast_cols_wide_dispatch(M, l)) return hipErrorInvalidValue;
     return l.err;
 }
 

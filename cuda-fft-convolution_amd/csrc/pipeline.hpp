@@ -32,7 +32,8 @@ struct Geometry {
     int T_cols = 1;            // columns per workgroup in the h-passes
     bool exact_window = false; // Lh == fft_h && Lw == fft_w: circular modulus equals the reference's
     FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
-    FastColsInfo fast_cols;    // specialised output kernel, if one exists for M (needs the exact window)
+    FastColsInfo fast_cols;    // specialised output kernel, if one exists for M
+    FastColsWideInfo fast_colw; // its 16-column variant (tiled intermediate only)
     // precombined + tiled intermediate: both hot kernels fast, 8-column tiles (fast_rows_pair.hpp)
     bool y_pre() const { return path_mode >= 3 && fast_rows.ok && fast_rows.RPW == 1 && fast_cols.ok && fast_cols.T == 8 && exact_window; }
     // 0 generic kernels only; 1 fast kernels, row-major intermediate; 2 (default) + tiled
@@ -41,6 +42,8 @@ struct Geometry {
     int path_mode = 2;
     // tiled intermediate: both hot kernels fast and the window a whole number of layout tiles
     bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
+    // the 16-column output kernel reads whole 128-byte rows of the 16-column tiled intermediate
+    bool use_wide() const { return y_tiled() && fast_colw.ok && y_tile_w == 16; }
     int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
     int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
     int y_row_order = 0;       // see make_fast_cols_tables
@@ -60,6 +63,7 @@ struct Tables {
     std::vector<PairEntry> pairs;
     FastRowsTables fr;  // only if Geometry::fast_rows.ok
     FastColsTables fcl; // only if Geometry::fast_cols.ok
+    FastColsWideTables fcw; // only if Geometry::fast_colw.ok
 };
 
 // returns false if the sizes are invalid / unsupported
@@ -102,6 +106,12 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M, prefer_T) : FastColsInfo();
     if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
     if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch, g.y_row_order);
+    // 16-column output kernel: correct but over the 168-VGPR budget of 3 waves/SIMD (spills: 86 us
+    // per map instead of 35), so off unless asked for; see DESIGN.md
+    bool wide_on = false;
+    if (const char* e = getenv("FFTCONV_COLS_WIDE")) wide_on = atoi(e) != 0;
+    g.fast_colw = (wide_on && g.fast_cols.ok) ? fast_cols_wide_lookup(g.M) : FastColsWideInfo();
+    if (g.fast_colw.ok) t.fcw = make_fast_cols_wide_tables(g.fast_colw, t.pm);
     return true;
 }
 
@@ -121,6 +131,11 @@ struct DeviceTables {
     const RowPair* fc_row_pairs = nullptr;
     const int* fc_lpos = nullptr;
     const int* fc_tile_lpos = nullptr;
+    // 16-column output kernel
+    const c32* cw_tw3 = nullptr; const c32* cw_twA = nullptr; const c32* cw_twF = nullptr;
+    const c32* cw_wh = nullptr; const c32* cw_wl = nullptr;
+    const unsigned* cw_ppA = nullptr; const unsigned* cw_ppB = nullptr;
+    const int* cw_tile_row_of = nullptr;
 };
 
 // image columns: planes = F, columns = W, valid samples = H
@@ -174,7 +189,8 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
     a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
     a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
-    a.y_row_of = g.y_tiled() ? d.fc_tile_row_of : nullptr; a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    a.y_row_of = g.y_tiled() ? (g.use_wide() ? d.cw_tile_row_of : d.fc_tile_row_of) : nullptr;
+    a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
     return a;
 }
 
@@ -205,6 +221,17 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
     a.y_precombined = g.y_pre() ? 1 : 0; a.lpos = g.y_pre() ? d.fc_lpos : d.fc_tile_lpos;
     if (g.y_pre()) a.y_tile_elems = g.M * 8;
+    return a;
+}
+
+inline FastColsWideArgs fast_cols_wide_args(const Geometry& g, const DeviceTables& d, const c32* Y, float* out,
+                                            size_t out_kernel_stride, int nk) {
+    FastColsWideArgs a{};
+    a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel();
+    a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
+    a.tiles_per_kernel = g.fft_w / 16; a.ntiles = a.tiles_per_kernel * nk;
+    a.tw3 = d.cw_tw3; a.twA = d.cw_twA; a.twF = d.cw_twF; a.wh = d.cw_wh; a.wl = d.cw_wl;
+    a.ppA = d.cw_ppA; a.ppB = d.cw_ppB;
     return a;
 }
 

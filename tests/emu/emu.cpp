@@ -103,6 +103,20 @@ struct EmuFastRowsPair {
     }
 };
 
+struct EmuFastColsWide {
+    const FastColsWideArgs& a;
+    c32* lds;
+    int nwg;
+    template <class Cfg>
+    void go() {
+        for (int wg = 0; wg < nwg; wg++) {
+            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+            HostPhaseCtx<ColWideState<Cfg>> ctx(Cfg::NT);
+            fast_cols_wide_body<Cfg>(ctx, lds, a, wg, nwg);
+        }
+    }
+};
+
 struct EmuFastCols {
     const FastColsArgs& a;
     c32* lds;
@@ -185,6 +199,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
         for (int plane = 0; plane < F; plane++)
             for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
         if (g.fast_cols.ok) d.fc_tile_row_of = t.fcl.tile_row_of.data();
+        if (g.fast_colw.ok) d.cw_tile_row_of = t.fcw.tile_row_of.data();
         if (g.fast_cols.ok) {
             d.fc_row_pairs = t.fcl.row_pairs.data();
             d.fc_lpos = t.fcl.lpos.data();
@@ -208,7 +223,14 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
             for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
         }
-        if (g.fast_cols.ok) {
+        if (g.use_wide()) {
+            d.cw_tw3 = t.fcw.tw3.data(); d.cw_twA = t.fcw.twA.data(); d.cw_twF = t.fcw.twF.data();
+            d.cw_wh = t.fcw.wh.data(); d.cw_wl = t.fcw.wl.data();
+            d.cw_ppA = t.fcw.ppA.data(); d.cw_ppB = t.fcw.ppB.data();
+            FastColsWideArgs fa = fast_cols_wide_args(g, d, Y.data(), out[k], 0, 1);
+            EmuFastColsWide run{fa, lds.data(), 3};
+            if (!fast_cols_wide_dispatch(g.M, run)) return -7;
+        } else if (g.fast_cols.ok) {
             d.fc_tw1 = t.fcl.tw1.data();
             d.fc_tw2 = t.fcl.tw2.data();
             d.fc_pairs = t.fcl.pairs.data();
