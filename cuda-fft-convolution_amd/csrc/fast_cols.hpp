@@ -68,6 +68,7 @@ struct FastColsArgs {
     int y_tiled;             // 1: Y is tiled [w / TL][p][TL] in this kernel's LDS order (fast_rows.hpp)
     int y_tile_elems;        // (M+1) * TL
     int y_tile_shift;        // log2(TL), TL = 8 or 16 (tiled, not precombined)
+    int y_pair_rows;         // 1 (with y_tiled): rows of bins (k, M-k) adjacent, M+2 rows per tile (mode 3)
     int y_precombined;       // 1: Y holds the merged rows Z (fast_rows_pair.hpp): M rows per 8-column tile,
                              //    contiguous, tile row u lands at LDS position lpos[u]; no pair pass here
     const int* lpos;         // LDS landing position of tile row u (precombined: M entries; tiled: M+1)
@@ -84,16 +85,28 @@ struct ColState {
     int off[C::UPT];     // Y row offsets (or, precombined, LDS landing positions) of this thread's gather units
 };
 
-// MODE: layout of the intermediate -- 0 row-major [i][y_pitch], 1 tiled, 2 precombined + tiled
-// (see FastColsArgs).  A template parameter so that each variant carries only its own address
+// MODE 3 (pair-adjacent rows, merge while landing): rows of bins k and M-k come as pairs
+template <class C>
+struct ColPairState {
+    static constexpr int NPU = (C::M / 2 + 1) * (C::T / 2);        // pair units (pair, 2 columns) per tile
+    static constexpr int RNDU = (NPU + C::NT - 1) / C::NT;
+    c32x2 pa[RNDU];      // row of bin k (or DC / middle)
+    c32x2 pb[RNDU];      // row of bin M-k (or Nyquist / padding)
+};
+
+// MODE: layout of the intermediate -- 0 row-major [i][y_pitch], 1 tiled, 2 precombined + tiled,
+// 3 tiled with the rows of bins (k, M-k) adjacent: one thread gathers both rows of a pair for two
+// columns and merges them in registers on the way into LDS, so the separate table-driven pair
+// pass over LDS (and its barrier) disappears (see FastColsArgs).  A template parameter so that each variant carries only its own address
 // arithmetic (the kernel sits right at the 168-VGPR budget of 3 waves per SIMD).
 template <class C, int MODE, class Ctx>
 FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
     constexpr bool PRE = (MODE == 2);
     constexpr bool TILED = (MODE == 1);
+    constexpr bool PLAND = (MODE == 3);
     constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
     constexpr int T2 = T / 2;
-    using State = ColState<C>;
+    using State = std::conditional_t<PLAND, ColPairState<C>, ColState<C>>;
     c32* tw2 = lds + C::OFF_T2;
     c32* tw1 = lds + C::OFF_T1;
     c32* wh = lds + C::OFF_WH;
@@ -120,7 +133,19 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     auto issue_gather = [&](int t, State& st, int tile) {
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
-        if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
+        if constexpr (PLAND) {   // rows 2p, 2p+1 = bins (p, M-p); one thread takes both for two columns
+            const int tw = 1 << g.y_tile_shift;
+            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 >> g.y_tile_shift) * g.y_tile_elems + (w0 & (tw - 1));
+            static_for<0, State::RNDU>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int e = t + NT * r;
+                if (e < State::NPU) {
+                    const c32* pr = Yt + ((size_t)(2 * (e / T2)) << g.y_tile_shift) + 2 * (e % T2);
+                    st.pa[r] = *reinterpret_cast<const c32x2*>(pr);
+                    st.pb[r] = *reinterpret_cast<const c32x2*>(pr + tw);
+                }
+            });
+        } else if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
             const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 / T) * g.y_tile_elems;
             static_for<0, C::UPT>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
@@ -150,6 +175,41 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         }
     };
     auto land_gather = [&](int t, State& st) {
+        if constexpr (PLAND) {
+            static_for<0, State::RNDU>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int e = t + NT * r;
+                if (e < State::NPU) {
+                    const int k = e / T2, t2 = e % T2;
+                    const unsigned pp = ppos[k];
+                    const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
+                    c32* z0 = lds + (2 * t2) * LP;
+                    c32* z1 = z0 + LP;
+                    const c32x2 xa = st.pa[r], xb = st.pb[r];
+                    if (k == 0) {                     // DC + Nyquist -> packed bin 0
+                        z0[pa] = mk(xa.a.x + xb.a.x, xa.a.x - xb.a.x);
+                        z1[pa] = mk(xa.b.x + xb.b.x, xa.b.x - xb.b.x);
+                    } else if (k == M / 2) {          // self-paired middle bin
+                        z0[pa] = mk(2.f * xa.a.x, -2.f * xa.a.y);
+                        z1[pa] = mk(2.f * xa.b.x, -2.f * xa.b.y);
+                    } else {
+                        const c32 w = cmul(wh[k >> 5], wl[k & 31]);
+                        {
+                            c32 S = mk(xa.a.x + xb.a.x, xa.a.y - xb.a.y), D = mk(xa.a.x - xb.a.x, xa.a.y + xb.a.y);
+                            c32 G = cmulc(D, w);
+                            z0[pa] = mk(S.x - G.y, S.y + G.x);
+                            z0[pb] = mk(S.x + G.y, G.x - S.y);
+                        }
+                        {
+                            c32 S = mk(xa.b.x + xb.b.x, xa.b.y - xb.b.y), D = mk(xa.b.x - xb.b.x, xa.b.y + xb.b.y);
+                            c32 G = cmulc(D, w);
+                            z1[pa] = mk(S.x - G.y, S.y + G.x);
+                            z1[pb] = mk(S.x + G.y, G.x - S.y);
+                        }
+                    }
+                }
+            });
+        } else {
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const int e = t + NT * r;
@@ -161,6 +221,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         if (!PRE && t < T2) {
             lds[(2 * t) * LP + M] = st.pre_ny.a;
             lds[(2 * t + 1) * LP + M] = st.pre_ny.b;
+        }
         }
     };
 
@@ -175,15 +236,15 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 if ((i & 31) == 0) wh[i >> 5] = e.w;      // w^(32*hi)
                 if (i < 32) wl[i] = e.w;                  // w^lo  (entry 0 holds w^0 = 1)
             }
+        if constexpr (!PLAND)
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             st.off[r] = (PRE || TILED) ? g.lpos[(t + NT * r) / T2] : g.rowoff[(t + NT * r) / T2];
         });
-        if (first_tile < g.ntiles) {
-            issue_gather(t, st, first_tile);
-            land_gather(t, st);
-        }
+        if (first_tile < g.ntiles) issue_gather(t, st, first_tile);
     });
+    // (the landing of mode 3 reads the tables written above: it needs the barrier in between)
+    if (first_tile < g.ntiles) ctx.phase([&](int t, State& st) { land_gather(t, st); });
 
     for (int it = 0;; it++) {
         const int tile = tile_of(it);
@@ -194,7 +255,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
 
         // C1: issue the next tile's gather (lands after C4), then merge the half spectrum of
         // this tile into the packed complex sequence, in place (table driven)
-        if constexpr (PRE) ctx.phase_nosync([&](int t, State& st) {
+        if constexpr (PRE || PLAND) ctx.phase_nosync([&](int t, State& st) {
             if (next < g.ntiles) issue_gather(t, st, next);
         });
         else ctx.phase([&](int t, State& st) {

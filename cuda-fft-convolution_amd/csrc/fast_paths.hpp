@@ -176,6 +176,7 @@ struct FastColsTables {
     std::vector<int> rowoff;       // M+1: Y row offset feeding LDS position p
     std::vector<int> tile_row_of;  // M+1: generic spectrum row i -> row of the tiled intermediate
     std::vector<int> tile_lpos;    // M+1: tile row -> LDS landing position in the output kernel
+    std::vector<int> pair_row_of;  // M+1: generic spectrum row i -> row of the pair-adjacent tile (mode 3)
     // precombined intermediate (fast_rows_pair.hpp): one RowPair per paired-row workgroup, and the
     // LDS landing position of every tile row
     std::vector<RowPair> row_pairs;  // M/2 + 1
@@ -219,6 +220,14 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
     }
     t.tile_row_of[fi.M] = fi.M;
     t.tile_lpos[fi.M] = fi.M;
+    // pair-adjacent tile rows (mode 3): pair p = (bin p, bin M-p) at rows 2p, 2p+1;
+    // p = 0: (DC, Nyquist); p = M/2: (middle bin, padding)
+    t.pair_row_of.assign(fi.M + 1, 0);
+    for (int k = 0; k < fi.M; k++) {
+        int r = (k <= fi.M / 2) ? 2 * k : 2 * (fi.M - k) + 1;
+        t.pair_row_of[generic.pos[k]] = r;
+    }
+    t.pair_row_of[fi.M] = 1;
     const int M = fi.M;
     t.lpos.assign(M, 0);
     for (int u = 0; u + 1 < M / 2; u++) {   // regular pairs k = u + 1

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_relayout_rows(RelayoutArgs a) {
 
 template <class Cfg, int MODE>
 __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols(FastColsArgs a) {
-    DevPhaseCtx<ColState<Cfg>> ctx;
+    DevPhaseCtx<std::conditional_t<MODE == 3, ColPairState<Cfg>, ColState<Cfg>>> ctx;
     fast_cols_body<Cfg, MODE>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -212,7 +212,8 @@ struct FastColsLauncher {
         if (a.y_precombined) {
             if constexpr (Cfg::T == 8) launch<Cfg, 2>();   // precombined tiles are 8 columns wide
             else err = hipErrorInvalidValue;
-        } else if (a.y_tiled) launch<Cfg, 1>();
+        } else if (a.y_tiled && a.y_pair_rows) launch<Cfg, 3>();
+        else if (a.y_tiled) launch<Cfg, 1>();
         else launch<Cfg, 0>();
     }
     template <class Cfg, int PRE>

@@ -42,6 +42,10 @@ struct Geometry {
     int path_mode = 2;
     // tiled intermediate: both hot kernels fast and the window a whole number of layout tiles
     bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
+    // tiled with the rows of bins (k, M-k) adjacent: the output kernel merges them while landing
+    bool y_pair_rows() const { return y_tiled() && pair_rows_on && !use_wide(); }
+    bool pair_rows_on = true;
+    int tile_rows() const { return y_pair_rows() ? M + 2 : rows; }
     // the 16-column output kernel reads whole 128-byte rows of the 16-column tiled intermediate
     bool use_wide() const { return y_tiled() && fast_colw.ok && y_tile_w == 16; }
     int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
@@ -52,7 +56,7 @@ struct Geometry {
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
         if (y_pre()) return (size_t)(fft_w / 8) * M * 8;
-        return y_tiled() ? (size_t)(fft_w / y_tile_w) * rows * y_tile_w : (size_t)rows * y_pitch;
+        return y_tiled() ? (size_t)(fft_w / y_tile_w) * tile_rows() * y_tile_w : (size_t)rows * y_pitch;
     }
     size_t map_elems() const { return (size_t)fft_h * fft_w; }
 };
@@ -76,6 +80,7 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e);
     if (const char* e = getenv("FFTCONV_ROWS_PERSIST")) g.rows_persistent = atoi(e) != 0;
     if (const char* e = getenv("FFTCONV_ROWS_ORDER")) g.rows_wg_order = atoi(e);
+    if (const char* e = getenv("FFTCONV_PAIR_ROWS")) g.pair_rows_on = atoi(e) != 0;
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
     g.fft_h = fft_size16(H + max_kh - 1);
@@ -131,6 +136,7 @@ struct DeviceTables {
     const RowPair* fc_row_pairs = nullptr;
     const int* fc_lpos = nullptr;
     const int* fc_tile_lpos = nullptr;
+    const int* fc_pair_row_of = nullptr;
     // 16-column output kernel
     const c32* cw_tw3 = nullptr; const c32* cw_twA = nullptr; const c32* cw_twF = nullptr;
     const c32* cw_wh = nullptr; const c32* cw_wl = nullptr;
@@ -189,8 +195,8 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
     a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
     a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
-    a.y_row_of = g.y_tiled() ? (g.use_wide() ? d.cw_tile_row_of : d.fc_tile_row_of) : nullptr;
-    a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    a.y_row_of = g.y_tiled() ? (g.use_wide() ? d.cw_tile_row_of : (g.y_pair_rows() ? d.fc_pair_row_of : d.fc_tile_row_of)) : nullptr;
+    a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
     return a;
 }
 
@@ -218,7 +224,8 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
     a.tiles_per_kernel = g.fft_w / g.fast_cols.T; a.ntiles = a.tiles_per_kernel * nk;
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
-    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.rows * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    a.y_pair_rows = g.y_pair_rows() ? 1 : 0;
     a.y_precombined = g.y_pre() ? 1 : 0; a.lpos = g.y_pre() ? d.fc_lpos : d.fc_tile_lpos;
     if (g.y_pre()) a.y_tile_elems = g.M * 8;
     return a;

@@ -125,6 +125,11 @@ struct EmuFastCols {
     void go() {
         for (int wg = 0; wg < nwg; wg++) {
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+            if (a.y_tiled && a.y_pair_rows && !a.y_precombined) {
+                HostPhaseCtx<ColPairState<Cfg>> pctx(Cfg::NT);
+                fast_cols_body<Cfg, 3>(pctx, lds, a, wg, nwg);
+                continue;
+            }
             HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
             if (a.y_precombined) {
                 if constexpr (Cfg::T == 8) fast_cols_body<Cfg, 2>(ctx, lds, a, wg, nwg);
@@ -204,6 +209,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fc_row_pairs = t.fcl.row_pairs.data();
             d.fc_lpos = t.fcl.lpos.data();
             d.fc_tile_lpos = t.fcl.tile_lpos.data();
+            d.fc_pair_row_of = t.fcl.pair_row_of.data();
         }
         if (g.y_pre()) {
             if (kw[k] > g.fast_rows.max_kw) return -4;

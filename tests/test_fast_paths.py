@@ -21,8 +21,9 @@ BOTH_SHAPE = (4096, 4096, 1, 127, 127, 1)
 OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 2048, 1, 63, 63, 1),
                 (4096, 300, 1, 63, 20, 1), (300, 4096, 2, 20, 63, 1), (1000, 1000, 3, 40, 50, 2),
                 (2000, 260, 1, 100, 29, 1), (250, 280, 2, 9, 9, 2)]
-VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent)
-    (0, 16, 0, 0), (1, 16, 0, 0), (1, 16, 0, 1), (2, 16, 0, 0), (2, 8, 0, 0), (2, 8, 1, 0), (2, 8, 2, 1), (2, 16, 2, 1), (3, 8, 0, 0)]
+VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent, pair_rows, cols_wide)
+    (0, 16, 0, 0, 1, 0), (1, 16, 0, 0, 1, 0), (1, 16, 0, 1, 1, 0), (2, 16, 0, 0, 1, 0), (2, 16, 0, 0, 0, 0),
+    (2, 8, 0, 0, 1, 0), (2, 8, 1, 0, 0, 0), (2, 8, 2, 1, 0, 0), (2, 16, 2, 1, 0, 0), (2, 16, 0, 0, 0, 1), (3, 8, 0, 0, 1, 0)]
 
 
 def make_inputs(shape, seed):
@@ -51,7 +52,10 @@ def emu_conv(emu, data, mkh, mkw, kernels):
 
 
 def set_variant(monkeypatch, v):
-    mode, tw, ro, pers = v
+    mode, tw, ro, pers = v[:4]
+    pair_rows, wide = (v[4], v[5]) if len(v) > 4 else (1, 0)
+    monkeypatch.setenv("FFTCONV_PAIR_ROWS", str(pair_rows))
+    monkeypatch.setenv("FFTCONV_COLS_WIDE", str(wide))
     monkeypatch.setenv("FFTCONV_TILE_W", str(tw))
     monkeypatch.setenv("FFTCONV_ROW_ORDER", str(ro))
     monkeypatch.setenv("FFTCONV_ROWS_PERSIST", str(pers))
