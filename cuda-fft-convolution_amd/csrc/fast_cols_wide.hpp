@@ -37,7 +37,9 @@ struct ColWideCfg {
     static constexpr int NB3 = R2 * R4;
     static constexpr int NB2 = m2;
     static constexpr int LP = ((H + 1 + 13) / 16) * 16 + 2;   // column pitch: >= H+1 (Nyquist slot), == 2 mod 16
-    static constexpr int UPT = (H * T) / (2 * NT);            // 16-byte gather units per thread and half
+    static constexpr int NUNIT = (H * T) / 2;                 // 16-byte gather units per half
+    static constexpr int UPT = (NUNIT + NT - 1) / NT;         // ... per thread
+    static constexpr int RND4 = (NB4 * T + NT - 1) / NT;
     static constexpr int RND3 = (NB3 * T + NT - 1) / NT;
     static constexpr int RND2 = (NB2 * T + NT - 1) / NT;
     static constexpr int NPA = H / 2 + 1;             // pair items of half A: DC, pairs k = 2i, middle (i = H/2)
@@ -56,8 +58,7 @@ struct ColWideCfg {
     static constexpr int LDS_ELEMS = OFF_PB + (NPB + 1) / 2;
     static constexpr int TILE_ROWS = 2 * H + 1;
     static_assert(R2 * R3 * R4 == H, "radices must multiply to H");
-    static_assert(NB4 * T == NT, "one radix-R4 butterfly per thread");
-    static_assert((H * T) % (2 * NT) == 0, "gather units must divide evenly");
+
     static_assert(R4 % 2 == 0 && H % 2 == 0, "16-byte LDS runs; pairs stay inside a half");
     static_assert(LDS_ELEMS * 8 <= 160 * 1024, "LDS budget");
 };
@@ -113,7 +114,7 @@ FC_HD void fast_cols_wide_body(Ctx& ctx, c32* lds, const FastColsWideArgs& g, in
         const c32* Yh = tile_base(tile) + (half ? (size_t)(H + 1) * T : 0);
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            st.pre[r] = *reinterpret_cast<const c32x2*>(Yh + 2 * (t + NT * r));
+            if (t + NT * r < C::NUNIT) st.pre[r] = *reinterpret_cast<const c32x2*>(Yh + 2 * (t + NT * r));
         });
         if (!half && t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Yh + (size_t)H * T + 2 * t);
     };
@@ -122,8 +123,10 @@ FC_HD void fast_cols_wide_body(Ctx& ctx, c32* lds, const FastColsWideArgs& g, in
             constexpr int r = decltype(r_)::value;
             const int e = t + NT * r;
             const int u = e / T2, t2 = e % T2;
-            lds[(2 * t2) * LP + u] = st.pre[r].a;
-            lds[(2 * t2 + 1) * LP + u] = st.pre[r].b;
+            if (e < C::NUNIT) {
+                lds[(2 * t2) * LP + u] = st.pre[r].a;
+                lds[(2 * t2 + 1) * LP + u] = st.pre[r].b;
+            }
         });
         if (!half && t < T2) {
             lds[(2 * t) * LP + H] = st.pre_ny.a;
@@ -161,8 +164,12 @@ FC_HD void fast_cols_wide_body(Ctx& ctx, c32* lds, const FastColsWideArgs& g, in
             }
         }
     };
-    auto stage_r4 = [&](int t) {   // radix R4 on contiguous runs, one butterfly per thread
-        const int col = t / C::NB4, q = t % C::NB4;
+    auto stage_r4 = [&](int t) {   // radix R4 on contiguous runs
+        FC_NOUNROLL
+        for (int r4 = 0; r4 < C::RND4; r4++) {
+        const int bi = t + NT * r4;
+        if (bi >= C::NB4 * T) break;
+        const int col = bi / C::NB4, q = bi % C::NB4;
         c32* p = lds + col * LP + q * R4;
         c32 v[R4];
         static_for<0, R4 / 2>([&](auto h_) {
@@ -179,6 +186,7 @@ FC_HD void fast_cols_wide_body(Ctx& ctx, c32* lds, const FastColsWideArgs& g, in
             w.b = v[2 * h + 1];
             *reinterpret_cast<c32x2*>(p + 2 * h) = w;
         });
+        }
     };
     auto stage_r3 = [&](int t) {   // radix R3, sub-length R4, blocks of m2
         FC_NOUNROLL

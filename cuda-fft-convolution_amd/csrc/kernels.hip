@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(2 * Cfg::NT, 3) k_fast_rows_pair(FastRowsPairA
 #endif
 
 template <class Cfg>
-__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols_wide(FastColsWideArgs a) {
+__global__ void __launch_bounds__(Cfg::NT, Cfg::NT / 256) k_fast_cols_wide(FastColsWideArgs a) {
     DevPhaseCtx<ColWideState<Cfg>> ctx;
     fast_cols_wide_body<Cfg>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
 }
