@@ -141,8 +141,8 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 const int e = t + NT * r;
                 if (e < State::NPU) {
                     const c32* pr = Yt + ((size_t)(2 * (e / T2)) << g.y_tile_shift) + 2 * (e % T2);
-                    st.pa[r] = *reinterpret_cast<const c32x2*>(pr);
-                    st.pb[r] = *reinterpret_cast<const c32x2*>(pr + tw);
+                    FC_STREAM_LOAD16(st.pa[r], pr);
+                    FC_STREAM_LOAD16(st.pb[r], pr + tw);
                 }
             });
         } else if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
@@ -360,7 +360,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     static_for<0, R1>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
                         if constexpr (FC_COLS_DBG & 8) { if (v[a].x == 1.2345e-30f) o[j + a * m1] = v[a]; }
-                        else if (j + a * m1 < nout) o[j + a * m1] = v[a];
+                        else if (j + a * m1 < nout) FC_STREAM_STORE(&o[j + a * m1], v[a]);
                     });
                 }
             }

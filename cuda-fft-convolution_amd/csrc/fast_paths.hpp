@@ -177,6 +177,7 @@ struct FastColsTables {
     std::vector<int> tile_row_of;  // M+1: generic spectrum row i -> row of the tiled intermediate
     std::vector<int> tile_lpos;    // M+1: tile row -> LDS landing position in the output kernel
     std::vector<int> pair_row_of;  // M+1: generic spectrum row i -> row of the pair-adjacent tile (mode 3)
+    std::vector<int> pair_row_seq; // M+1: spectrum rows sorted by pair_row_of (processing order of the persistent row kernel)
     // precombined intermediate (fast_rows_pair.hpp): one RowPair per paired-row workgroup, and the
     // LDS landing position of every tile row
     std::vector<RowPair> row_pairs;  // M/2 + 1
@@ -228,6 +229,12 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
         t.pair_row_of[generic.pos[k]] = r;
     }
     t.pair_row_of[fi.M] = 1;
+    {
+        std::vector<int> inv(fi.M + 2, -1);
+        for (int i = 0; i <= fi.M; i++) inv[t.pair_row_of[i]] = i;
+        for (int r = 0; r < fi.M + 2; r++)
+            if (inv[r] >= 0) t.pair_row_seq.push_back(inv[r]);
+    }
     const int M = fi.M;
     t.lpos.assign(M, 0);
     for (int u = 0; u + 1 < M / 2; u++) {   // regular pairs k = u + 1

@@ -22,6 +22,9 @@
 #include "butterflies.hpp"
 #include "fc_common.hpp"
 
+#ifndef FC_NT_SLOADS
+#define FC_NT_SLOADS 0   // 1: streaming loads for the image-spectrum rows (A/B)
+#endif
 #ifndef FC_ROWS1_DBG
 #define FC_ROWS1_DBG 0   // timing experiments only (wrong results): 1 no stores, 2 no S loads, 4 no final phase
 #endif
@@ -76,6 +79,7 @@ struct FastRowsArgs {
     const int* y_row_of;
     int y_tile_elems;        // (M+1) * TL
     int y_tile_shift;        // log2(TL)
+    const int* row_seq;      // persistent variant: j-th row to process (nullptr: identity)
 };
 
 template <class C, bool MULTIF>
@@ -96,10 +100,6 @@ FC_HD void power_chain(c32 w, c32 (&p)[R]) {
         else p[c] = cmul(p[c - 1], w);
     });
 }
-
-struct alignas(16) c32x2 {
-    c32 a, b;
-};
 
 // kw must satisfy kw <= min(m1, NZ2*R3) (checked at plan time / by the launcher).
 template <class C>
@@ -137,7 +137,12 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, 
                 const c32* srow = sbase + (size_t)(row0 + rr) * g.s_pitch;
                 static_for<0, R3 / 2>([&](auto h_) {
                     constexpr int h = decltype(h_)::value;
-                    c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
+                    c32x2 v;
+#if FC_NT_SLOADS
+                    FC_STREAM_LOAD16(v, srow + (size_t)(h * C::NB3 + q) * 2);
+#else
+                    v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
+#endif
                     st.s[2 * h] = v.a;
                     st.s[2 * h + 1] = v.b;
                 });
@@ -280,8 +285,8 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, 
                     constexpr int a = decltype(a_)::value;
                     int w = j + a * m1;
                     if ((FC_ROWS1_DBG & 1) ? (v[a].x == 1.2345e-30f) : (w < g.wout)) {
-                        if (tiled) yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))] = v[a];
-                        else yrow[w] = v[a];
+                        if (tiled) FC_STREAM_STORE(&yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))], v[a]);
+                        else FC_STREAM_STORE(&yrow[w], v[a]);
                     }
                 });
             }
@@ -311,8 +316,11 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
     const int kw = g.kw;
     if (item0 >= item1) return;
 
+    // item = kernel*rows + j; the j-th row processed is row_seq[j] (tile order: consecutive
+    // items write adjacent rows of the tiled intermediate)
     auto issue_loads = [&](int t, State& st, int item, int f) {
-        const int kernel = item / rows, row = item - kernel * rows;
+        const int kernel = item / rows;
+        const int row = FC_UNIFORM(g.row_seq ? g.row_seq[item - kernel * rows] : item - kernel * rows);
         const c32* arow = g.A + (size_t)kernel * g.a_kernel_stride + (size_t)f * g.a_feat_stride + (size_t)row * g.a_pitch;
         const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)row * g.s_pitch;
         static_for<0, XR>([&](auto r_) {
@@ -337,7 +345,8 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
     });
 
     for (int item = item0; item < item1; item++) {
-        const int kernel = item / rows, row = item - kernel * rows;
+        const int kernel = item / rows;
+        const int row = FC_UNIFORM(g.row_seq ? g.row_seq[item - kernel * rows] : item - kernel * rows);
         for (int f = 0; f < nF; f++) {
             if (MULTIF && f > 0) ctx.phase_nosync([&](int t, State& st) { issue_loads(t, st, item, f); });
 
@@ -360,8 +369,8 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
 
             // P2: forward stage 2
             ctx.phase([&](int t, State&) {
-                FC_NOUNROLL
-                for (int r = 0; r < C::RND2; r++) {   // one butterfly at a time: the prefetched rows stay in registers
+                static_for<0, C::RND2>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
                     int u = t + NT * r;
                     if (u < C::NB2) {
                         int c1 = u / R3, b = u - c1 * R3;
@@ -379,7 +388,7 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
                             p[c * R3] = cmul(v[c], tw2[(c - 1) * R3 + b]);
                         });
                     }
-                }
+                });
             });
 
             // P3: forward stage 3, product, (feature sum,) inverse stage 3 -- in registers
@@ -422,15 +431,10 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
             });
         }
 
-        // the registers holding this item's kernel row and spectrum row are dead: reuse them for
-        // the next item, whose loads now overlap P4, P5 and the next P1, P2
-        if (item + 1 < item1)
-            ctx.phase_nosync([&](int t, State& st) { issue_loads(t, st, item + 1, 0); });
-
         // P4: inverse stage 2
         ctx.phase([&](int t, State&) {
-            FC_NOUNROLL
-            for (int r = 0; r < C::RND2; r++) {
+            static_for<0, C::RND2>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
                 int u = t + NT * r;
                 if (u < C::NB2) {
                     int c1 = u / R3, b = u - c1 * R3;
@@ -447,17 +451,27 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
                         p[a * R3] = v[a];
                     });
                 }
-            }
+            });
         });
+
+        // The registers that held this item's kernel row and spectrum row are dead since P3: the
+        // next item's loads go into them now -- after the register-hungry P4 -- and fly during P5
+        // and the next P1, P2 (the same live range a row has in the plain kernel).
+        // (unconditional -- the last item reloads itself -- so that the old values are provably dead
+        // during P4 and the registers are shared)
+        {
+            const int nxt = (item + 1 < item1) ? item + 1 : item;
+            ctx.phase_nosync([&](int t, State& st) { issue_loads(t, st, nxt, 0); });
+        }
 
         // P5: inverse stage 1 straight to global memory; the closing barrier protects the LDS
         // row against the next item's P1
         const bool tiled = g.y_row_of != nullptr;
         c32* yrow = g.Y + (size_t)kernel * g.y_kernel_stride +
-                    (tiled ? ((size_t)g.y_row_of[row] << g.y_tile_shift) : (size_t)row * g.y_pitch);
+                    (tiled ? ((size_t)FC_UNIFORM(g.y_row_of[row]) << g.y_tile_shift) : (size_t)row * g.y_pitch);
         ctx.phase([&](int t, State&) {
             FC_NOUNROLL
-            for (int r = 0; r < C::RND1; r++) {
+            for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the next item's rows are in registers
                 int j = t + NT * r;
                 if (j < C::NB1) {
                     c32 p[R1];

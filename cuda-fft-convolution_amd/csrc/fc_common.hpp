@@ -24,6 +24,47 @@
 #define FC_NOUNROLL
 #endif
 
+// A value that is the same in every lane of the wave but that the compiler cannot prove uniform
+// (e.g. loaded from a table at a uniform index): readfirstlane moves it to an SGPR, which keeps
+// the addresses built from it scalar (no VGPR pairs, no waterfall loops).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define FC_UNIFORM(x) (x)
+#endif
+
+// Streaming store of one complex value: the intermediate and the maps are written once and not
+// re-read by this kernel (FC_NT_STORES=0 restores plain stores for A/B runs).
+#ifndef FC_NT_STORES
+#define FC_NT_STORES 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && FC_NT_STORES
+#define FC_STREAM_STORE(ptr, val)                                                          \
+    do {                                                                                   \
+        const ::fc::c32 fc_v_ = (val);                                                     \
+        typedef float fc_f2_ __attribute__((ext_vector_type(2)));                          \
+        fc_f2_ fc_t_ = {fc_v_.x, fc_v_.y};                                                 \
+        __builtin_nontemporal_store(fc_t_, reinterpret_cast<fc_f2_*>(ptr));                \
+    } while (0)
+#else
+#define FC_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
+// Streaming 16-byte load (data read exactly once): FC_NT_LOADS=0 restores plain loads for A/B runs.
+#ifndef FC_NT_LOADS
+#define FC_NT_LOADS 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && FC_NT_LOADS
+#define FC_STREAM_LOAD16(dst, ptr)                                                         \
+    do {                                                                                   \
+        typedef float fc_f4_ __attribute__((ext_vector_type(4)));                          \
+        const fc_f4_ fc_t_ = __builtin_nontemporal_load(reinterpret_cast<const fc_f4_*>(ptr)); \
+        (dst).a.x = fc_t_.x; (dst).a.y = fc_t_.y; (dst).b.x = fc_t_.z; (dst).b.y = fc_t_.w;  \
+    } while (0)
+#else
+#define FC_STREAM_LOAD16(dst, ptr) ((dst) = *reinterpret_cast<const ::fc::c32x2*>(ptr))
+#endif
+
 // Scheduling fence (device only): keeps the compiler from interleaving the unrolled rounds of a
 // phase, which multiplies their register footprint.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -60,6 +101,10 @@ FC_HD void static_for(F&& f) {
         static_for<B + 1, E>(f);
     }
 }
+
+struct alignas(16) c32x2 {
+    c32 a, b;
+};
 
 constexpr int FC_MAX_STAGES = 12;
 

@@ -109,7 +109,7 @@ struct fftconv_plan {
     DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
-    DevBuf<int> fc_rowoff, fc_tile_row_of, fc_lpos, fc_tile_lpos, fc_pair_row_of;
+    DevBuf<int> fc_rowoff, fc_tile_row_of, fc_lpos, fc_tile_lpos, fc_pair_row_of, fc_pair_row_seq;
     DevBuf<RowPair> fc_row_pairs;
     DevBuf<c32> cw_tw3, cw_twA, cw_twF, cw_wh, cw_wl;
     DevBuf<unsigned> cw_ppA, cw_ppB;
@@ -168,7 +168,7 @@ struct fftconv_plan {
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
         S0.release(); fr_tw1.release(); fr_tw2.release(); fr_map.release();
-        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release(); fc_pair_row_of.release();
+        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release(); fc_pair_row_of.release(); fc_pair_row_seq.release();
         cw_tw3.release(); cw_twA.release(); cw_twF.release(); cw_wh.release(); cw_wl.release();
         cw_ppA.release(); cw_ppB.release(); cw_tile_row_of.release();
     }
@@ -370,6 +370,9 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
             if ((rc = p->fc_pair_row_of.ensure(ft.pair_row_of.size()))) break;
             if ((rc = cp(p->fc_pair_row_of.p, ft.pair_row_of.data(), ft.pair_row_of.size() * sizeof(int)))) break;
             p->d.fc_pair_row_of = p->fc_pair_row_of.p;
+            if ((rc = p->fc_pair_row_seq.ensure(ft.pair_row_seq.size()))) break;
+            if ((rc = cp(p->fc_pair_row_seq.p, ft.pair_row_seq.data(), ft.pair_row_seq.size() * sizeof(int)))) break;
+            p->d.fc_pair_row_seq = p->fc_pair_row_seq.p;
             p->d.fc_row_pairs = p->fc_row_pairs.p;
         }
         if (p->g.fast_colw.ok) {

@@ -137,6 +137,7 @@ struct DeviceTables {
     const int* fc_lpos = nullptr;
     const int* fc_tile_lpos = nullptr;
     const int* fc_pair_row_of = nullptr;
+    const int* fc_pair_row_seq = nullptr;
     // 16-column output kernel
     const c32* cw_tw3 = nullptr; const c32* cw_twA = nullptr; const c32* cw_twF = nullptr;
     const c32* cw_wh = nullptr; const c32* cw_wl = nullptr;
@@ -197,6 +198,7 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
     a.y_row_of = g.y_tiled() ? (g.use_wide() ? d.cw_tile_row_of : (g.y_pair_rows() ? d.fc_pair_row_of : d.fc_tile_row_of)) : nullptr;
     a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
+    a.row_seq = (g.rows_persistent && g.y_pair_rows()) ? d.fc_pair_row_seq : nullptr;
     return a;
 }
 

@@ -210,6 +210,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fc_lpos = t.fcl.lpos.data();
             d.fc_tile_lpos = t.fcl.tile_lpos.data();
             d.fc_pair_row_of = t.fcl.pair_row_of.data();
+            d.fc_pair_row_seq = t.fcl.pair_row_seq.data();
         }
         if (g.y_pre()) {
             if (kw[k] > g.fast_rows.max_kw) return -4;
