@@ -204,14 +204,18 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
         return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel width %d exceeds what this plan's row kernel accepts (%d)", kw,
                     g.fast_rows.max_kw);
     const size_t per_a = (size_t)g.F * g.rows * a_pitch_for(kw);  // c32 per kernel
-    const size_t a_budget = (size_t)256 << 20;
-    int nbA = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, a_budget / (per_a * sizeof(c32))));
     const size_t y_bytes = g.y_elems_per_kernel() * sizeof(c32);
+    // maps per spectral/output launch.  auto: enough to amortise the last partially filled wave
+    // of workgroups (the two hot kernels run ~2 "rounds" of workgroups per map on 256 CUs; 32 maps
+    // make both round counts nearly integral at cfg3), capped at 2.5 GiB of intermediate
     int nbY = (int)p->opt_batch_maps;
-    // auto: enough maps per launch to amortise the last partially filled wave of workgroups
-    // (the two hot kernels run ~2 "rounds" of workgroups per map on 256 CUs), capped at 1.25 GiB
-    if (nbY <= 0) nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)1280 << 20) / y_bytes));
-    nbY = std::min(nbY, nbA);
+    if (nbY <= 0) nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)2560 << 20) / y_bytes));
+    nbY = std::min(nbY, n);
+    // kernels per column-spectrum chunk: a multiple of nbY within 512 MiB
+    const size_t a_budget = (size_t)512 << 20;
+    int nbA = (int)std::max<size_t>(1, a_budget / (per_a * sizeof(c32)));
+    nbA = std::max(nbY, nbA / nbY * nbY);
+    nbA = std::min(nbA, (n + nbY - 1) / nbY * nbY);
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
     const bool staged = (sink.packed == nullptr);
@@ -399,7 +403,6 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
             if ((rc = p->fr_tw1.ensure(fr.tw1.size()))) break;
             if ((rc = p->fr_tw2.ensure(fr.tw2.size()))) break;
             if ((rc = p->fr_map.ensure(fr.relayout.size()))) break;
-            if ((rc = p->S0.ensure(p->g.spectrum_elems()))) break;
             if ((rc = cp(p->fr_tw1.p, fr.tw1.data(), fr.tw1.size() * sizeof(c32)))) break;
             if ((rc = cp(p->fr_tw2.p, fr.tw2.data(), fr.tw2.size() * sizeof(c32)))) break;
             if ((rc = cp(p->fr_map.p, fr.relayout.data(), fr.relayout.size() * sizeof(int)))) break;
@@ -455,9 +458,8 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         HIP_TRY(hipMemcpyAsync(p->I.p, data, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
         dimg = p->I.p;
     }
-    // with the fast row kernel the generic passes work in a scratch buffer and a final
-    // permutation writes the spectrum in the register order that kernel reads
-    c32* sgen = g.fast_rows.ok ? p->S0.p : p->spec();
+    // (with the fast row kernel the w-pass stores the spectrum directly in that kernel's register order)
+    c32* sgen = p->spec();
     ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_COLS, g.F)) return rc;
     HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
@@ -465,10 +467,6 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
     RowsFwdArgs ra = image_rows_args(g, p->t, p->d, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_ROWS, g.F)) return rc;
     HIP_TRY(launch_rows_fwd(ra, g.F * g.rows, rows_threads(g), (size_t)g.Lw * sizeof(c32), p->stream));
-    if (g.fast_rows.ok) {
-        RelayoutArgs rl = relayout_args(g, p->d, sgen, p->spec());
-        HIP_TRY(launch_relayout_rows(rl, g.F * g.rows, p->stream));
-    }
     if (int rc = p->prof_end()) return rc;
     if (location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
     p->have_image = true;

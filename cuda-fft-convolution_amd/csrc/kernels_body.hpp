@@ -106,6 +106,8 @@ struct RowsFwdArgs {
     float scale;
     FftDesc fd;      // Lw-point transform
     const c32* tw;
+    const int* out_map;  // optional: element x of the stored row is transform position out_map[x]
+                         // (the fast row kernel's register order, fast_rows.hpp); nullptr = identity
 };
 
 template <class Ctx>
@@ -115,7 +117,11 @@ FC_HD void rows_fwd_body(const Ctx& ctx, c32* lds, const RowsFwdArgs& a, int row
     for (int x = ctx.tid; x < L; x += ctx.nthreads) lds[x] = (x < a.nvalid) ? g[x] : mk(0.f, 0.f);
     ctx.sync();
     fft_forward(ctx, lds, L, 1, a.fd, a.tw);
-    for (int x = ctx.tid; x < L; x += ctx.nthreads) g[x] = scale(lds[x], a.scale);
+    if (a.out_map) {
+        for (int x = ctx.tid; x < L; x += ctx.nthreads) g[x] = scale(lds[a.out_map[x]], a.scale);
+    } else {
+        for (int x = ctx.tid; x < L; x += ctx.nthreads) g[x] = scale(lds[x], a.scale);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

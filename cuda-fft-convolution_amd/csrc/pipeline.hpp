@@ -161,6 +161,7 @@ inline RowsFwdArgs image_rows_args(const Geometry& g, const Tables& t, const Dev
     a.S = S; a.pitch = g.s_pitch; a.nvalid = g.W;
     a.scale = (float)(1.0 / ((double)g.Lh * (double)g.Lw));
     a.fd = t.pw.desc; a.tw = d.tw_w;
+    a.out_map = g.fast_rows.ok ? d.fr_relayout : nullptr;   // store straight in the fast row kernel's order
     return a;
 }
 

@@ -169,14 +169,9 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
     ColsR2CArgs ia = image_cols_args(g, t, d, data, S);
     for (int plane = 0; plane < F; plane++)
         for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
+    if (g.fast_rows.ok) d.fr_relayout = t.fr.relayout.data();   // w-pass stores in the fast row kernel's order
     RowsFwdArgs ra = image_rows_args(g, t, d, S);
     for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
-    if (g.fast_rows.ok) {  // generic position order -> register order of the fast row kernel
-        std::vector<c32> tmp(S, S + g.spectrum_elems());
-        d.fr_relayout = t.fr.relayout.data();
-        RelayoutArgs rl = relayout_args(g, d, tmp.data(), S);
-        for (int r = 0; r < F * g.rows; r++) relayout_rows_body(ctx, rl, r);
-    }
     return 0;
 }
 
