@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--check", action="store_true", help="verify a few maps against the oracle after timing")
+    ap.add_argument("--no-overlap", action="store_true", help="blocking broadcast, no kernel-column overlap (A/B)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +100,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fc = util.load_package()
@@ -128,14 +133,21 @@ def main():
     def step():
         if rank == 0:
             plan.set_image_device(img_d.data_ptr())
-        if world > 1:
-            dist.broadcast(spec, src=0)
+        if use_dist:
+            # the kernels' column transforms do not need the image: they run while the spectrum
+            # travels (rank 0: after its image pass; the others: from the start of the step)
+            if args.no_overlap:
+                dist.broadcast(spec, src=0)
+            else:
+                work = dist.broadcast(spec, src=0, async_op=True)
+                plan.prepare_kernels_packed_device(nf, kern_d.data_ptr(), kh, kw)
+                work.wait()        # the plan's stream waits for the broadcast, the host does not
         plan.mark_spectrum_valid()
         plan.convolve_packed_device(nf, kern_d.data_ptr(), kh, kw, out.data_ptr())
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -147,7 +159,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -224,12 +236,20 @@ def main():
                 g = out[j].cpu().numpy().T  # [w][h] -> h x w
                 errs.append(util.rel_err(g, r))
             result["check_max_rel_err"] = max(errs)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
     plan.destroy()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which would otherwise be flushed after
+        # Python's output at exit: flush it first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -64,7 +64,8 @@ EXPORTED_SYMBOLS = (
     "fftconv_convolution_fft", "fftconv_plan_create", "fftconv_plan_destroy", "fftconv_plan_get_info",
     "fftconv_plan_set_image", "fftconv_plan_spectrum", "fftconv_plan_mark_spectrum_valid",
     "fftconv_plan_use_spectrum_buffer",
-    "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_synchronize",
+    "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_prepare_kernels_packed",
+    "fftconv_plan_synchronize",
     "fftconv_plan_set_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
 )
 
@@ -118,6 +119,7 @@ def load_library():
     lib.fftconv_plan_use_spectrum_buffer.argtypes = [vp, vp, cs]
     lib.fftconv_plan_convolve.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci]
     lib.fftconv_plan_convolve_packed.argtypes = [vp, ci, vp, ci, ci, vp]
+    lib.fftconv_plan_prepare_kernels_packed.argtypes = [vp, ci, vp, ci, ci]
     lib.fftconv_plan_synchronize.argtypes = [vp]
     lib.fftconv_plan_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
     lib.fftconv_plan_get_profile.argtypes = [vp, ctypes.POINTER(Profile), ci]
@@ -268,6 +270,12 @@ class Plan:
         asynchronous on the plan's stream."""
         _check(self._lib.fftconv_plan_convolve_packed(self._h, int(n), ctypes.c_void_p(int(kernels_ptr)),
                                                       int(kh), int(kw), ctypes.c_void_p(int(out_ptr))))
+
+    def prepare_kernels_packed_device(self, n, kernels_ptr, kh, kw):
+        """queue the image-independent part of convolve_packed_device (kernel column transforms);
+        the next convolve_packed_device call with the same arguments reuses it"""
+        _check(self._lib.fftconv_plan_prepare_kernels_packed(self._h, int(n), ctypes.c_void_p(int(kernels_ptr)),
+                                                             int(kh), int(kw)))
 
     def synchronize(self):
         _check(self._lib.fftconv_plan_synchronize(self._h))

@@ -92,7 +92,7 @@ struct FastRowsTables {
     Plan1D plan;               // radices (R1, R2, R3)
     std::vector<c32> tw1;      // w_L^j, j < m1
     std::vector<c32> tw2;      // stage-2 table
-    std::vector<int> relayout; // register-order index -> generic position (see relayout_rows_body)
+    std::vector<int> relayout; // register-order index -> generic position (RowsFwdArgs::out_map)
 };
 
 inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D& generic) {

@@ -12,7 +12,7 @@
 //     per butterfly (pure twiddle scaling) and stage 2 reads only its first NZ2 inputs;
 //   * stage-1 twiddles are one table entry + an in-register power chain, stage-2 twiddles a
 //     small LDS table; no integer division by run-time values anywhere.
-// The image spectrum is read in the "register order" layout written by relayout_rows_body:
+// The image spectrum is read in the "register order" layout (rows_fwd_body stores it that way):
 // element a of stage-3 butterfly q at ((a>>1)*NB3 + q)*2 + (a&1), i.e. 16 B per lane, fully
 // coalesced.
 //
@@ -495,26 +495,6 @@ FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int
             }
         });
     }
-}
-
-// ---------------------------------------------------------------------------------------
-// relayout_rows: one-off permutation of the image spectrum rows from the generic kernels'
-// digit-reversed position order into the register order the fast kernel reads:
-//   dst[row][i] = src[row][map[i]]
-// ---------------------------------------------------------------------------------------
-struct RelayoutArgs {
-    const c32* src;
-    c32* dst;
-    int src_pitch, dst_pitch;
-    int n;            // elements per row
-    const int* map;   // n entries
-};
-
-template <class Ctx>
-FC_HD void relayout_rows_body(const Ctx& ctx, const RelayoutArgs& a, int row) {
-    const c32* s = a.src + (size_t)row * a.src_pitch;
-    c32* d = a.dst + (size_t)row * a.dst_pitch;
-    for (int i = ctx.tid; i < a.n; i += ctx.nthreads) d[i] = s[a.map[i]];
 }
 
 }  // namespace fc

@@ -104,7 +104,6 @@ struct fftconv_plan {
     DevBuf<float> K;   // packed kernels staged on the device
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
-    DevBuf<c32> S0;    // image spectrum in generic order before the relayout (fast rows only)
     DevBuf<c32> fr_tw1, fr_tw2;
     DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
@@ -117,6 +116,8 @@ struct fftconv_plan {
     int num_cus = 256;
     long opt_batch_maps = 0;
     bool profile = false;
+    // kernel column spectra of the first chunk already in A (fftconv_plan_prepare_kernels_packed)
+    struct { const float* dk = nullptr; int n = 0, kh = 0, kw = 0; } prepared;
     std::vector<EventPair> pending;
     std::vector<EventPair> pool;
     double prof_ms[PK_COUNT] = {0, 0, 0, 0, 0};
@@ -167,7 +168,7 @@ struct fftconv_plan {
         pool.clear();
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
-        S0.release(); fr_tw1.release(); fr_tw2.release(); fr_map.release();
+        fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release(); fc_pair_row_of.release(); fc_pair_row_seq.release();
         cw_tw3.release(); cw_twA.release(); cw_twF.release(); cw_wh.release(); cw_wl.release();
         cw_ppA.release(); cw_ppB.release(); cw_tile_row_of.release();
@@ -188,11 +189,33 @@ struct Sink {
     int location = FFTCONV_DEVICE;  // of ptrs
 };
 
-// Core of the per-kernel loop (src/cudaConvolutionFFT.cu:204-291) for n kernels of one size,
-// packed on the device at dk ([n][F][kw][kh]).
-int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
+struct BatchSizes {
+    size_t per_a;  // c32 of column spectrum per kernel
+    int nbY;       // maps per spectral/output launch
+    int nbA;       // kernels per column-spectrum chunk (a multiple of nbY)
+};
+
+BatchSizes batch_sizes(const fftconv_plan* p, int n, int kw) {
     const Geometry& g = p->g;
-    if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
+    BatchSizes b;
+    b.per_a = (size_t)g.F * g.rows * a_pitch_for(kw);
+    const size_t y_bytes = g.y_elems_per_kernel() * sizeof(c32);
+    // maps per launch.  auto: enough to amortise the last partially filled wave of workgroups (the
+    // two hot kernels run ~2 "rounds" of workgroups per map on 256 CUs; 32 maps make both round
+    // counts nearly integral at cfg3), capped at 2.5 GiB of intermediate
+    b.nbY = (int)p->opt_batch_maps;
+    if (b.nbY <= 0) b.nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)2560 << 20) / y_bytes));
+    b.nbY = std::min(b.nbY, n);
+    // kernels per column-spectrum chunk: a multiple of nbY within 512 MiB
+    const size_t a_budget = (size_t)512 << 20;
+    b.nbA = (int)std::max<size_t>(1, a_budget / (b.per_a * sizeof(c32)));
+    b.nbA = std::max(b.nbY, b.nbA / b.nbY * b.nbY);
+    b.nbA = std::min(b.nbA, (n + b.nbY - 1) / b.nbY * b.nbY);
+    return b;
+}
+
+int check_kernel_size(const fftconv_plan* p, int kh, int kw) {
+    const Geometry& g = p->g;
     if (kh < 1 || kw < 1 || kh > g.fft_h || kw > g.fft_w)  // src/cudaConvolutionFFT.cu:242
         return fail(FFTCONV_ERR_KERNEL_SHAPE,
                     "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
@@ -203,19 +226,27 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
     if (g.fast_rows.ok && kw > g.fast_rows.max_kw)
         return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel width %d exceeds what this plan's row kernel accepts (%d)", kw,
                     g.fast_rows.max_kw);
-    const size_t per_a = (size_t)g.F * g.rows * a_pitch_for(kw);  // c32 per kernel
-    const size_t y_bytes = g.y_elems_per_kernel() * sizeof(c32);
-    // maps per spectral/output launch.  auto: enough to amortise the last partially filled wave
-    // of workgroups (the two hot kernels run ~2 "rounds" of workgroups per map on 256 CUs; 32 maps
-    // make both round counts nearly integral at cfg3), capped at 2.5 GiB of intermediate
-    int nbY = (int)p->opt_batch_maps;
-    if (nbY <= 0) nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)2560 << 20) / y_bytes));
-    nbY = std::min(nbY, n);
-    // kernels per column-spectrum chunk: a multiple of nbY within 512 MiB
-    const size_t a_budget = (size_t)512 << 20;
-    int nbA = (int)std::max<size_t>(1, a_budget / (per_a * sizeof(c32)));
-    nbA = std::max(nbY, nbA / nbY * nbY);
-    nbA = std::min(nbA, (n + nbY - 1) / nbY * nbY);
+    return 0;
+}
+
+// h-transform of the kernels [a0, a0 + na) of a packed group into the column-spectrum buffer A
+int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh, int kw) {
+    const Geometry& g = p->g;
+    ColsR2CArgs ka = kernel_cols_args(g, p->t, p->d, dk + (size_t)a0 * g.F * kh * kw, kh, kw, p->A.p);
+    if (int rc = p->prof_begin(PK_KERNEL_COLS, na)) return rc;
+    HIP_TRY(launch_cols_r2c(ka, tiles_for(kw, g.T_cols), na * g.F, cols_threads(g), p->cols_lds(), p->stream));
+    return p->prof_end();
+}
+
+// Core of the per-kernel loop (src/cudaConvolutionFFT.cu:204-291) for n kernels of one size,
+// packed on the device at dk ([n][F][kw][kh]).
+int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
+    const Geometry& g = p->g;
+    if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
+    if (int rc = check_kernel_size(p, kh, kw)) return rc;
+    const BatchSizes bs = batch_sizes(p, n, kw);
+    const size_t per_a = bs.per_a;
+    const int nbY = bs.nbY, nbA = bs.nbA;
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
     const bool staged = (sink.packed == nullptr);
@@ -226,10 +257,10 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
     const int cthreads = cols_threads(g), rthreads = rows_threads(g);
     for (int a0 = 0; a0 < n; a0 += nbA) {
         const int na = std::min(nbA, n - a0);
-        ColsR2CArgs ka = kernel_cols_args(g, p->t, p->d, dk + (size_t)a0 * g.F * kh * kw, kh, kw, p->A.p);
-        if (int rc = p->prof_begin(PK_KERNEL_COLS, na)) return rc;
-        HIP_TRY(launch_cols_r2c(ka, tiles_for(kw, T), na * g.F, cthreads, p->cols_lds(), p->stream));
-        if (int rc = p->prof_end()) return rc;
+        const bool have_cols = (a0 == 0 && p->prepared.dk == dk && p->prepared.n == n && p->prepared.kh == kh && p->prepared.kw == kw);
+        p->prepared.dk = nullptr;   // A is about to be consumed / overwritten
+        if (!have_cols)
+            if (int rc = launch_kernel_cols(p, dk, a0, na, kh, kw)) return rc;
         for (int y0 = 0; y0 < na; y0 += nbY) {
             const int ny = std::min(nbY, na - y0);
             if (int rc = p->prof_begin(PK_SPECTRAL, ny)) return rc;
@@ -509,6 +540,22 @@ int fftconv_plan_convolve_packed(fftconv_plan* plan, int n_kernel, const float* 
     return run_group(plan, n_kernel, kernels_device, kernel_h, kernel_w, sink);
 }
 
+int fftconv_plan_prepare_kernels_packed(fftconv_plan* plan, int n_kernel, const float* kernels_device, int kernel_h,
+                                        int kernel_w) {
+    if (!plan || n_kernel < 0) return fail(FFTCONV_ERR_INVALID_ARG, "Wrong number of inputs");
+    if (n_kernel == 0) return 0;
+    if (!kernels_device) return fail(FFTCONV_ERR_INVALID_ARG, "NULL kernel pointer");
+    fftconv_plan* p = plan;
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_kernel_size(p, kernel_h, kernel_w)) return rc;
+    const BatchSizes bs = batch_sizes(p, n_kernel, kernel_w);
+    if (int rc = p->A.ensure(bs.per_a * bs.nbA)) return rc;
+    p->prepared.dk = nullptr;
+    if (int rc = launch_kernel_cols(p, kernels_device, 0, std::min(bs.nbA, n_kernel), kernel_h, kernel_w)) return rc;
+    p->prepared.dk = kernels_device; p->prepared.n = n_kernel; p->prepared.kh = kernel_h; p->prepared.kw = kernel_w;
+    return 0;
+}
+
 int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* kernels, const int* kernel_h,
                           const int* kernel_w, int kernel_location, float* const* out, int out_location) {
     if (!plan || n_kernel < 0) return fail(FFTCONV_ERR_INVALID_ARG, "Wrong number of inputs");
@@ -557,7 +604,7 @@ int fftconv_plan_synchronize(fftconv_plan* plan) {
 
 int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
-    if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; return 0; }
+    if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
     return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
 }

@@ -107,11 +107,6 @@ __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_persist(FastRowsArgs a
     fast_rows_persist_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, rows, item0, item1);
 }
 
-__global__ void __launch_bounds__(256) k_relayout_rows(RelayoutArgs a) {
-    DevCtx ctx{(int)threadIdx.x, (int)blockDim.x};
-    relayout_rows_body(ctx, a, (int)blockIdx.x);
-}
-
 template <class Cfg, int MODE>
 __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols(FastColsArgs a) {
     DevPhaseCtx<std::conditional_t<MODE == 3, ColPairState<Cfg>, ColState<Cfg>>> ctx;
@@ -316,12 +311,6 @@ hipError_t launch_fast_cols_wide(int M, const FastColsWideArgs& a, int num_cus, 
     FastColsWideLauncher l{a, num_cus, s};
     if (!fast_cols_wide_dispatch(M, l)) return hipErrorInvalidValue;
     return l.err;
-}
-
-hipError_t launch_relayout_rows(const RelayoutArgs& a, int rows, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_relayout_rows, dim3(rows), dim3(256), 0, s, a);
-    return hipGetLastError();
 }
 
 hipError_t kernels_init() {

@@ -19,7 +19,6 @@ hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int
 hipError_t launch_fast_rows_pair(int L, int nz2, const FastRowsPairArgs& a, int pairs, int kernels, hipStream_t s);
 hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_fast_cols_wide(int M, const FastColsWideArgs& a, int num_cus, hipStream_t s);
-hipError_t launch_relayout_rows(const RelayoutArgs& a, int rows, hipStream_t s);
 hipError_t launch_cols_c2r(const ColsC2RArgs& a, int tiles, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 
 }  // namespace fc

@@ -212,13 +212,6 @@ inline FastRowsPairArgs fast_rows_pair_args(const Geometry& g, const DeviceTable
     return a;
 }
 
-// image spectrum: generic position order (src) -> register order (dst), all F*rows rows
-inline RelayoutArgs relayout_args(const Geometry& g, const DeviceTables& d, const c32* src, c32* dst) {
-    RelayoutArgs a{};
-    a.src = src; a.dst = dst; a.src_pitch = g.s_pitch; a.dst_pitch = g.s_pitch; a.n = g.Lw; a.map = d.fr_relayout;
-    return a;
-}
-
 // fast output columns: nk kernels of the current batch
 inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, const c32* Y, float* out,
                                    size_t out_kernel_stride, int nk) {

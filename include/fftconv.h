@@ -154,6 +154,14 @@ int fftconv_plan_convolve(fftconv_plan *plan, int n_kernel,
 int fftconv_plan_convolve_packed(fftconv_plan *plan, int n_kernel, const float *kernels_device,
                                  int kernel_h, int kernel_w, float *out_device);
 
+/* Optional split of fftconv_plan_convolve_packed: queues only the part that does not depend on
+ * the image (the h-transform of the kernels' columns, i.e. padData + the H half of cufftExecR2C on
+ * the kernels, src/cudaConvolutionFFT.cu:245-255) so that it overlaps the arrival of the image
+ * spectrum (the RCCL broadcast on the other ranks).  The next fftconv_plan_convolve_packed call
+ * with the same arguments reuses it; any other use of the plan discards it. */
+int fftconv_plan_prepare_kernels_packed(fftconv_plan *plan, int n_kernel, const float *kernels_device,
+                                        int kernel_h, int kernel_w);
+
 /* Block until everything queued on the plan's stream has finished. */
 int fftconv_plan_synchronize(fftconv_plan *plan);
 

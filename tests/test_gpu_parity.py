@@ -167,6 +167,31 @@ def test_device_resident_packed_path(fc, oracle):
                     assert util.rel_err(got[j].T, ref[j]) < TIGHT
 
 
+def test_prepare_kernels_split(fc, oracle):
+    """the image-independent half of the packed convolution queued ahead (what overlaps the
+    broadcast on the other ranks); a call with other arguments must not reuse it"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H, W, F, kh, kw, n = 200, 180, 2, 11, 9, 5
+    img, ks = util.synth(51, H, W, F, kh, kw, n)
+    k_d = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in ks]))).to(dev)
+    k2_d = (k_d * 2.0).contiguous()
+    ref = oracle.conv_fft(img, kh, kw, ks)
+    with fc.Plan(H, W, F, kh, kw) as p:
+        out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+        p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)     # before the image exists
+        p.set_image(img)
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+        for j in range(n):
+            assert util.rel_err(out[j].cpu().numpy().T, ref[j]) < TIGHT
+        p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+        p.convolve_packed_device(n, k2_d.data_ptr(), kh, kw, out.data_ptr())   # different kernels: recomputed
+        p.synchronize()
+        for j in range(n):
+            assert util.rel_err(out[j].cpu().numpy().T, 2.0 * ref[j]) < TIGHT
+
+
 def test_external_spectrum_buffer_roundtrip(fc, oracle):
     """the multi-GPU hand-off: spectrum produced into caller memory by one plan, consumed by another"""
     torch = pytest.importorskip("torch")
