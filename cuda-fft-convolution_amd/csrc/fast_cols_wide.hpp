@@ -59,7 +59,7 @@ struct ColWideCfg {
     static constexpr int TILE_ROWS = 2 * H + 1;
     static_assert(R2 * R3 * R4 == H, "radices must multiply to H");
 
-    static_assert(R4 % 2 == 0 && H % 2 == 0, "16-byte LDS runs; pairs stay inside a half");
+    static_assert(H % 2 == 0, "pairs stay inside a half");
     static_assert(LDS_ELEMS * 8 <= 160 * 1024, "LDS budget");
 };
 
@@ -172,20 +172,26 @@ FC_HD void fast_cols_wide_body(Ctx& ctx, c32* lds, const FastColsWideArgs& g, in
         const int col = bi / C::NB4, q = bi % C::NB4;
         c32* p = lds + col * LP + q * R4;
         c32 v[R4];
-        static_for<0, R4 / 2>([&](auto h_) {
-            constexpr int h = decltype(h_)::value;
-            c32x2 w = *reinterpret_cast<const c32x2*>(p + 2 * h);
-            v[2 * h] = w.a;
-            v[2 * h + 1] = w.b;
-        });
-        Dft<R4, +1>::run(v);
-        static_for<0, R4 / 2>([&](auto h_) {
-            constexpr int h = decltype(h_)::value;
-            c32x2 w;
-            w.a = v[2 * h];
-            w.b = v[2 * h + 1];
-            *reinterpret_cast<c32x2*>(p + 2 * h) = w;
-        });
+        if constexpr (R4 % 2 == 0) {   // runs are 16-byte aligned: wide LDS accesses
+            static_for<0, R4 / 2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                c32x2 w = *reinterpret_cast<const c32x2*>(p + 2 * h);
+                v[2 * h] = w.a;
+                v[2 * h + 1] = w.b;
+            });
+            Dft<R4, +1>::run(v);
+            static_for<0, R4 / 2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                c32x2 w;
+                w.a = v[2 * h];
+                w.b = v[2 * h + 1];
+                *reinterpret_cast<c32x2*>(p + 2 * h) = w;
+            });
+        } else {                       // odd radix: 8-byte accesses, lane stride R4*8 B is conflict-free
+            static_for<0, R4>([&](auto a_) { v[decltype(a_)::value] = p[decltype(a_)::value]; });
+            Dft<R4, +1>::run(v);
+            static_for<0, R4>([&](auto a_) { p[decltype(a_)::value] = v[decltype(a_)::value]; });
+        }
         }
     };
     auto stage_r3 = [&](int t) {   // radix R3, sub-length R4, blocks of m2
@@ -280,15 +286,18 @@ FC_HD void fast_cols_wide_body(Ctx& ctx, c32* lds, const FastColsWideArgs& g, in
                     c32 v[R2];
                     stage_r2(col, jp, v);
                     const c32 wf = twF[jp];   // w_M^j'
-                    c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.fft_h);
+                    // 32-bit element offsets from the (uniform) map base: one VGPR per address
+                    // instead of a 64-bit pair for each of the 2*R2*RND2 stores
+                    c32* omap = reinterpret_cast<c32*>(out);
+                    const unsigned off0 = (unsigned)(w0 + col) * (unsigned)nout + (unsigned)jp;
                     static_for<0, R2>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
                         // conj(w_M^(j' + a*m2)) = conj(w_M^j') * exp(+2 pi i a / (2*R2))
                         const c32 vb = mul_root<2 * R2, a, +1>(cmulc(v[a], wf));
                         const c32 va = st.ua[r][a];
                         const int j = jp + a * m2;
-                        if (j < nout) o[j] = va + vb;
-                        if (j + H < nout) o[j + H] = va - vb;
+                        if (j < nout) FC_STREAM_STORE(&omap[off0 + (unsigned)(a * m2)], va + vb);
+                        if (j + H < nout) FC_STREAM_STORE(&omap[off0 + (unsigned)(a * m2 + H)], va - vb);
                     });
                 }
                 FC_SCHED_FENCE();

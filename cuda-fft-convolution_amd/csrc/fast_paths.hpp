@@ -267,8 +267,10 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
 // 16-column output kernel (fast_cols_wide.hpp): X(H, R2, R3, R4, NT), transform M = 2H.
 //   M = 2112 = 2 x (6 x 8 x 22): the cfg3 / cfg4 output pass.
 // ---------------------------------------------------------------------------------------
+//   (8 x 12 x 11: the in-register radix is kept small -- the kernel holds a whole half tile plus a
+//    prefetched one in registers and must stay under the 168 VGPRs of 3 waves per SIMD)
 #define FC_FAST_COLW_CONFIGS(X) \
-    X(1056, 6, 8, 22, 768)
+    X(1056, 8, 12, 11, 768)
 
 struct FastColsWideInfo {
     bool ok = false;
