@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fast_cols.hpp"
+#include "fast_cols_fwd.hpp"
 #include "fast_cols_wide.hpp"
 #include "fast_rows.hpp"
 #include "fast_rows_pair.hpp"
@@ -156,6 +157,28 @@ template <class Runner>
 inline bool fast_rows_pair_dispatch(int L, int nz2_needed, Runner&& run) { return fast_rows_rpw1_dispatch(L, nz2_needed, run); }
 
 inline bool fast_cols_length(int M) { return fast_cols_lookup(M).ok; }
+
+// Forward column kernel (fast_cols_fwd.hpp): same configurations; NZ2 = 3 (pruned, short kernels)
+// or R2 (any input length).  run.template go<Cfg, NZ2>().
+template <class Runner>
+inline bool fast_cols_fwd_dispatch(int M, int T, bool pruned, Runner&& run) {
+#define FC_X(MM, A, B, C, TT, NTT)                                       \
+    if (M == MM && T == TT) {                                            \
+        if (pruned) run.template go<ColCfg<MM, A, B, C, TT, NTT>, 3>();  \
+        else run.template go<ColCfg<MM, A, B, C, TT, NTT>, B>();         \
+        return true;                                                     \
+    }
+    FC_FAST_COL_CONFIGS(FC_X)
+#undef FC_X
+    return false;
+}
+
+// may the pruned variant take columns of h_in samples?  (one non-zero input per stage-1 butterfly,
+// at most 3 non-zero inputs per stage-2 butterfly)
+inline bool fast_cols_fwd_pruned_ok(const FastColsInfo& fi, int h_in) {
+    const int nz = (h_in + 1) / 2, m1 = fi.M / fi.R1;
+    return fi.R2 > 3 && nz <= m1 && nz <= 3 * fi.R3;
+}
 
 template <class Runner>
 inline bool fast_cols_dispatch(int M, int T, Runner&& run) {

@@ -232,9 +232,15 @@ int check_kernel_size(const fftconv_plan* p, int kh, int kw) {
 // h-transform of the kernels [a0, a0 + na) of a packed group into the column-spectrum buffer A
 int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh, int kw) {
     const Geometry& g = p->g;
-    ColsR2CArgs ka = kernel_cols_args(g, p->t, p->d, dk + (size_t)a0 * g.F * kh * kw, kh, kw, p->A.p);
     if (int rc = p->prof_begin(PK_KERNEL_COLS, na)) return rc;
-    HIP_TRY(launch_cols_r2c(ka, tiles_for(kw, g.T_cols), na * g.F, cols_threads(g), p->cols_lds(), p->stream));
+    if (g.fast_fwd) {
+        FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dk + (size_t)a0 * g.F * kh * kw, (size_t)kh * kw, kh, kh, kw, na * g.F,
+                                                p->A.p, (size_t)g.rows * a_pitch_for(kw), a_pitch_for(kw));
+        HIP_TRY(launch_fast_cols_fwd(g.M, g.fast_cols.T, fast_cols_fwd_pruned_ok(g.fast_cols, kh), fa, p->num_cus, p->stream));
+    } else {
+        ColsR2CArgs ka = kernel_cols_args(g, p->t, p->d, dk + (size_t)a0 * g.F * kh * kw, kh, kw, p->A.p);
+        HIP_TRY(launch_cols_r2c(ka, tiles_for(kw, g.T_cols), na * g.F, cols_threads(g), p->cols_lds(), p->stream));
+    }
     return p->prof_end();
 }
 
@@ -491,9 +497,15 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
     }
     // (with the fast row kernel the w-pass stores the spectrum directly in that kernel's register order)
     c32* sgen = p->spec();
-    ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_COLS, g.F)) return rc;
-    HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
+    if (g.fast_fwd) {
+        FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dimg, (size_t)g.H * g.W, g.H, g.H, g.W, g.F, sgen,
+                                                (size_t)g.rows * g.s_pitch, g.s_pitch);
+        HIP_TRY(launch_fast_cols_fwd(g.M, g.fast_cols.T, false, fa, p->num_cus, p->stream));
+    } else {
+        ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, sgen);
+        HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
+    }
     if (int rc = p->prof_end()) return rc;
     RowsFwdArgs ra = image_rows_args(g, p->t, p->d, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_ROWS, g.F)) return rc;

@@ -39,6 +39,20 @@ __global__ void __launch_bounds__(512) k_cols_c2r(ColsC2RArgs a) {
     cols_c2r_body(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// Raises the dynamic-LDS limit of a kernel once per device (the attribute is per device; a
+// process may drive several GPUs through different plans).
+template <class K>
+hipError_t ensure_lds_attr(K kernel, unsigned long long& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask & bit) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done_mask |= bit;
+    return e;
+}
+
 // ---- fast path -------------------------------------------------------------------------
 template <class State>
 struct DevPhaseCtx {
@@ -150,16 +164,37 @@ struct FastColsWideLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg>
     void go() {
-        static bool attr_set = false;
+        static unsigned long long attr_mask = 0;
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
-        if (!attr_set) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cols_wide<Cfg>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (err != hipSuccess) return;
-            attr_set = true;
-        }
+        err = ensure_lds_attr(k_fast_cols_wide<Cfg>, attr_mask);
+        if (err != hipSuccess) return;
         const int grid = a.ntiles < num_cus ? a.ntiles : num_cus;   // persistent, one workgroup per CU
         hipLaunchKernelGGL((k_fast_cols_wide<Cfg>), dim3(grid), dim3(Cfg::NT), lds, s, a);
+        err = hipGetLastError();
+    }
+};
+
+template <class Cfg, int NZ2>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols_fwd(FastColsFwdArgs a) {
+    DevPhaseCtx<ColFwdState> ctx;
+    fast_cols_fwd_body<Cfg, NZ2>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+struct FastColsFwdLauncher {
+    const FastColsFwdArgs& a;
+    int num_cus;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg, int NZ2>
+    void go() {
+        static unsigned long long attr_mask = 0;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        err = ensure_lds_attr(k_fast_cols_fwd<Cfg, NZ2>, attr_mask);
+        if (err != hipSuccess) return;
+        const int per_cu = (int)((size_t)(160 * 1024) / lds) < 768 / Cfg::NT ? (int)((size_t)(160 * 1024) / lds) : 768 / Cfg::NT;
+        const int want = num_cus * (per_cu < 1 ? 1 : per_cu);
+        const int grid = a.ntiles < want ? a.ntiles : want;
+        hipLaunchKernelGGL((k_fast_cols_fwd<Cfg, NZ2>), dim3(grid), dim3(Cfg::NT), lds, s, a);
         err = hipGetLastError();
     }
 };
@@ -176,14 +211,10 @@ struct FastRowsPairLauncher {
     }
     template <class Cfg, int NZ2, bool MULTIF>
     void launch() {
-        static bool attr_set = false;
+        static unsigned long long attr_mask = 0;
         const size_t lds = (size_t)(2 * (Cfg::L + 16) + Cfg::T2N + Cfg::m1) * sizeof(c32);
-        if (!attr_set) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows_pair<Cfg, NZ2, MULTIF>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (err != hipSuccess) return;
-            attr_set = true;
-        }
+        err = ensure_lds_attr(k_fast_rows_pair<Cfg, NZ2, MULTIF>, attr_mask);
+        if (err != hipSuccess) return;
         FastRowsPairArgs aa = a;
         aa.nk = kernels;
         aa.npairs = pairs;
@@ -213,14 +244,10 @@ struct FastColsLauncher {
     }
     template <class Cfg, int PRE>
     void launch() {
-        static bool attr_set = false;
+        static unsigned long long attr_mask = 0;
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
-        if (!attr_set) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_cols<Cfg, PRE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (err != hipSuccess) return;
-            attr_set = true;
-        }
+        err = ensure_lds_attr(k_fast_cols<Cfg, PRE>, attr_mask);
+        if (err != hipSuccess) return;
         // persistent: as many workgroups as fit at once (LDS-limited), one or two per CU
         const int per_cu = (int)((size_t)(160 * 1024) / lds) < 768 / Cfg::NT ? (int)((size_t)(160 * 1024) / lds) : 768 / Cfg::NT;
         const int want = max_wg * (per_cu < 1 ? 1 : per_cu);
@@ -251,14 +278,10 @@ struct FastRowsLauncher {
     }
     template <class Cfg, int NZ2, bool MULTIF>
     void launch_persist() {
-        static bool attr_set = false;
+        static unsigned long long attr_mask = 0;
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
-        if (!attr_set) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows_persist<Cfg, NZ2, MULTIF>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (err != hipSuccess) return;
-            attr_set = true;
-        }
+        err = ensure_lds_attr(k_fast_rows_persist<Cfg, NZ2, MULTIF>, attr_mask);
+        if (err != hipSuccess) return;
         const int total = rows * kernels;
         const int grid = total < persist_wgs ? total : persist_wgs;
         hipLaunchKernelGGL((k_fast_rows_persist<Cfg, NZ2, MULTIF>), dim3(grid), dim3(Cfg::NT), lds, s, a, rows, total);
@@ -266,14 +289,10 @@ struct FastRowsLauncher {
     }
     template <class Cfg, int NZ2, bool MULTIF>
     void launch() {
-        static bool attr_set = false;
+        static unsigned long long attr_mask = 0;
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
-        if (!attr_set) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows<Cfg, NZ2, MULTIF>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (err != hipSuccess) return;
-            attr_set = true;
-        }
+        err = ensure_lds_attr(k_fast_rows<Cfg, NZ2, MULTIF>, attr_mask);
+        if (err != hipSuccess) return;
         const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
         dim3 grid(groups, kernels);
         if (order == 1) grid = dim3(groups * kernels);
@@ -303,6 +322,13 @@ hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hi
     if (a.ntiles <= 0) return hipSuccess;
     FastColsLauncher l{a, num_cus, s};
     if (!fast_cols_dispatch(M, T, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+hipError_t launch_fast_cols_fwd(int M, int T, bool pruned, const FastColsFwdArgs& a, int num_cus, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    FastColsFwdLauncher l{a, num_cus, s};
+    if (!fast_cols_fwd_dispatch(M, T, pruned, l)) return hipErrorInvalidValue;
     return l.err;
 }
 

@@ -18,6 +18,7 @@ hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels
 hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, int order, hipStream_t s);
 hipError_t launch_fast_rows_pair(int L, int nz2, const FastRowsPairArgs& a, int pairs, int kernels, hipStream_t s);
 hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_fast_cols_fwd(int M, int T, bool pruned, const FastColsFwdArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_fast_cols_wide(int M, const FastColsWideArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_cols_c2r(const ColsC2RArgs& a, int tiles, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 

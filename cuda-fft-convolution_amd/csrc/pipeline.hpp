@@ -34,6 +34,8 @@ struct Geometry {
     FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
     FastColsInfo fast_cols;    // specialised output kernel, if one exists for M
     FastColsWideInfo fast_colw; // its 16-column variant (tiled intermediate only)
+    bool fast_fwd = false;     // forward column transforms (image, kernels) by fast_cols_fwd.hpp: the
+                               // spectrum rows are then in the fast plan's order, not the generic plan's
     // precombined + tiled intermediate: both hot kernels fast, 8-column tiles (fast_rows_pair.hpp)
     bool y_pre() const { return path_mode >= 3 && fast_rows.ok && fast_rows.RPW == 1 && fast_cols.ok && fast_cols.T == 8 && exact_window; }
     // 0 generic kernels only; 1 fast kernels, row-major intermediate; 2 (default) + tiled
@@ -110,13 +112,18 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (const char* e = getenv("FFTCONV_COLS_T")) prefer_T = atoi(e);                          // A/B runs only
     g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M, prefer_T) : FastColsInfo();
     if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
-    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, t.pm, g.y_pitch, g.y_row_order);
+    bool fwd_on = true;
+    if (const char* e = getenv("FFTCONV_FAST_FWD")) fwd_on = atoi(e) != 0;                     // A/B runs only
+    g.fast_fwd = g.fast_cols.ok && fwd_on;
+    // the plan whose digit-reversed order the spectrum rows are produced in
+    Plan1D producer = g.fast_fwd ? make_plan1d_seq(g.M, {g.fast_cols.R1, g.fast_cols.R2, g.fast_cols.R3}) : t.pm;
+    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, producer, g.y_pitch, g.y_row_order);
     // 16-column output kernel: correct but over the 168-VGPR budget of 3 waves/SIMD (spills: 86 us
     // per map instead of 35), so off unless asked for; see DESIGN.md
     bool wide_on = false;
     if (const char* e = getenv("FFTCONV_COLS_WIDE")) wide_on = atoi(e) != 0;
     g.fast_colw = (wide_on && g.fast_cols.ok) ? fast_cols_wide_lookup(g.M) : FastColsWideInfo();
-    if (g.fast_colw.ok) t.fcw = make_fast_cols_wide_tables(g.fast_colw, t.pm);
+    if (g.fast_colw.ok) t.fcw = make_fast_cols_wide_tables(g.fast_colw, producer);
     return true;
 }
 
@@ -235,6 +242,18 @@ inline FastColsWideArgs fast_cols_wide_args(const Geometry& g, const DeviceTable
     a.tiles_per_kernel = g.fft_w / 16; a.ntiles = a.tiles_per_kernel * nk;
     a.tw3 = d.cw_tw3; a.twA = d.cw_twA; a.twF = d.cw_twF; a.wh = d.cw_wh; a.wl = d.cw_wl;
     a.ppA = d.cw_ppA; a.ppB = d.cw_ppB;
+    return a;
+}
+
+// forward column pass of `planes` planes of `ncols` columns with h_in valid samples each
+inline FastColsFwdArgs fast_cols_fwd_args(const Geometry& g, const DeviceTables& d, const float* in, size_t in_plane_stride,
+                                          int in_col_pitch, int h_in, int ncols, int planes, c32* out,
+                                          size_t out_plane_stride, int out_pitch) {
+    FastColsFwdArgs a{};
+    a.in = in; a.in_plane_stride = in_plane_stride; a.in_col_pitch = in_col_pitch; a.h_in = h_in; a.ncols = ncols;
+    a.out = out; a.out_plane_stride = out_plane_stride; a.out_pitch = out_pitch;
+    a.tiles_per_plane = (ncols + g.fast_cols.T - 1) / g.fast_cols.T; a.ntiles = a.tiles_per_plane * planes;
+    a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
     return a;
 }
 

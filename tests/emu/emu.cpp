@@ -103,6 +103,20 @@ struct EmuFastRowsPair {
     }
 };
 
+struct EmuFastColsFwd {
+    const FastColsFwdArgs& a;
+    c32* lds;
+    int nwg;
+    template <class Cfg, int NZ2>
+    void go() {
+        for (int wg = 0; wg < nwg; wg++) {
+            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+            HostPhaseCtx<ColFwdState> ctx(Cfg::NT);
+            fast_cols_fwd_body<Cfg, NZ2>(ctx, lds, a, wg, nwg);
+        }
+    }
+};
+
 struct EmuFastColsWide {
     const FastColsWideArgs& a;
     c32* lds;
@@ -166,9 +180,16 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
     c32* S = reinterpret_cast<c32*>(spec_out);
     // garbage-fill to catch reads of never-written cells
     for (size_t i = 0; i < g.spectrum_elems(); i++) S[i] = mk(1e30f, -1e30f);
-    ColsR2CArgs ia = image_cols_args(g, t, d, data, S);
-    for (int plane = 0; plane < F; plane++)
-        for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
+    if (g.fast_fwd) {
+        d.fc_tw1 = t.fcl.tw1.data(); d.fc_tw2 = t.fcl.tw2.data(); d.fc_pairs = t.fcl.pairs.data();
+        FastColsFwdArgs fa = fast_cols_fwd_args(g, d, data, (size_t)H * W, H, H, W, F, S, (size_t)g.rows * g.s_pitch, g.s_pitch);
+        EmuFastColsFwd run{fa, lds.data(), 3};
+        if (!fast_cols_fwd_dispatch(g.M, g.fast_cols.T, false, run)) return -8;
+    } else {
+        ColsR2CArgs ia = image_cols_args(g, t, d, data, S);
+        for (int plane = 0; plane < F; plane++)
+            for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
+    }
     if (g.fast_rows.ok) d.fr_relayout = t.fr.relayout.data();   // w-pass stores in the fast row kernel's order
     RowsFwdArgs ra = image_rows_args(g, t, d, S);
     for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
@@ -195,9 +216,17 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
         std::vector<c32> A((size_t)F * g.rows * a_pitch_for(kw[k]));
         for (auto& v : A) v = mk(1e30f, -1e30f);
         for (auto& v : Y) v = mk(1e30f, -1e30f);
-        ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
-        for (int plane = 0; plane < F; plane++)
-            for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
+        if (g.fast_fwd) {
+            d.fc_tw1 = t.fcl.tw1.data(); d.fc_tw2 = t.fcl.tw2.data(); d.fc_pairs = t.fcl.pairs.data();
+            FastColsFwdArgs fa = fast_cols_fwd_args(g, d, kernels[k], (size_t)kh[k] * kw[k], kh[k], kh[k], kw[k], F, A.data(),
+                                                    (size_t)g.rows * a_pitch_for(kw[k]), a_pitch_for(kw[k]));
+            EmuFastColsFwd run{fa, lds.data(), 2};
+            if (!fast_cols_fwd_dispatch(g.M, g.fast_cols.T, fast_cols_fwd_pruned_ok(g.fast_cols, kh[k]), run)) return -8;
+        } else {
+            ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
+            for (int plane = 0; plane < F; plane++)
+                for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
+        }
         if (g.fast_cols.ok) d.fc_tile_row_of = t.fcl.tile_row_of.data();
         if (g.fast_colw.ok) d.cw_tile_row_of = t.fcw.tile_row_of.data();
         if (g.fast_cols.ok) {
