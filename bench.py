@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--check", action="store_true", help="verify a few maps against the oracle after timing")
+    ap.add_argument("--images", type=int, default=0,
+                    help="streamed mode (BASELINE configs[4]): each rank convolves this many images per step, every "
+                         "image with its own kernels' maps, the next image's H2D copy (pinned host memory, side "
+                         "stream) overlapped with the current image's compute; no collective")
     ap.add_argument("--no-overlap", action="store_true", help="blocking broadcast, no kernel-column overlap (A/B)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
@@ -130,10 +134,44 @@ def main():
     if args.batch_maps:
         plan.set_option("batch_maps", args.batch_maps)
 
+    streamed = args.images > 0
+    if streamed:
+        # images of this rank in pinned host memory (seeded per global image index), two device
+        # buffers, a side stream for the copies
+        n_img = args.images
+        imgs_h = []
+        for i in range(n_img):
+            a = np.random.default_rng(1234 + seed + 1000 * (rank * n_img + i)).random((F, W, H), dtype=np.float32)
+            imgs_h.append(torch.from_numpy(a).pin_memory())
+        img_buf = [torch.empty((F, W, H), dtype=torch.float32, device=dev) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(dev)
+        copied = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def step_streamed():
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(copy_stream):
+            img_buf[0].copy_(imgs_h[0], non_blocking=True)
+            copied[0].record(copy_stream)
+        for i in range(n_img):
+            b = i & 1
+            if i + 1 < n_img:            # next image's H2D while this one is convolved
+                with torch.cuda.stream(copy_stream):
+                    if i >= 1:
+                        copy_stream.wait_event(consumed[1 - b])   # its buffer was read by image i-1's FFT
+                    img_buf[1 - b].copy_(imgs_h[i + 1], non_blocking=True)
+                    copied[1 - b].record(copy_stream)
+            main.wait_event(copied[b])
+            plan.set_image_device(img_buf[b].data_ptr())
+            consumed[b].record(main)
+            plan.convolve_packed_device(nf, kern_d.data_ptr(), kh, kw, out.data_ptr())
+
     def step():
+        if streamed:
+            return step_streamed()
         if rank == 0:
             plan.set_image_device(img_d.data_ptr())
-        if use_dist:
+        if use_dist and not streamed:
             # the kernels' column transforms do not need the image: they run while the spectrum
             # travels (rank 0: after its image pass; the others: from the start of the step)
             if args.no_overlap:
@@ -195,7 +233,7 @@ def main():
                 traffic = per_map * per[dom]["units_per_launch"] if per_map else None
             except Exception:
                 traffic = None
-        total_maps = nf * world
+        total_maps = nf * world * (args.images if streamed else 1)
         value = total_maps * P * args.steps / dt / 1e9
         result = {
             "metric": "Gpixel-filters/s (padded FFT size)",
@@ -210,10 +248,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: %dx%d image (F=%d), %d kernels of %dx%d per GPU -> %d maps of %dx%d, filter-sharded"
-                                   % (args.config, H, W, F, nf, kh, kw, total_maps, info.fft_h, info.fft_w),
+            "config": {"workload": "%s: %dx%d image (F=%d), %d kernels of %dx%d per GPU -> %d maps of %dx%d, %s"
+                                   % (args.config, H, W, F, nf, kh, kw, total_maps, info.fft_h, info.fft_w,
+                                      "image-sharded" if streamed else "filter-sharded"),
                        "transform": [info.transform_h, info.transform_w],
-                       "filters_per_gpu": nf, "parallelism": "filters x%d + 1 bcast" % world if world > 1 else "single GPU"},
+                       "filters_per_gpu": nf,
+                       "images_per_gpu_per_step": args.images if streamed else 1,
+                       "parallelism": ("images x%d, streamed H2D" % world) if streamed else
+                                      ("filters x%d + 1 bcast" % world if world > 1 else "single GPU")},
             "hbm_algorithmic_gbps": ab["total"] * total_maps * args.steps / dt / 1e9,
             "hbm_frac_of_peak": ab["total"] * total_maps * args.steps / dt / 1e9 / (HBM_PEAK_GBPS * world),
             "kernels": per,
@@ -230,7 +272,10 @@ def main():
             orc = util.Oracle()
             idx = sorted(set([0, nf // 2, nf - 1]))
             ks = [np.asfortranarray(np.transpose(kern_h[j], (2, 1, 0))) for j in idx]
-            ref = orc.conv_fft(img_h, kh, kw, ks)
+            img_chk = img_h
+            if streamed:   # the maps in `out` belong to the last image of the step
+                img_chk = np.asfortranarray(np.transpose(imgs_h[-1].numpy(), (2, 1, 0)))
+            ref = orc.conv_fft(img_chk, kh, kw, ks)
             errs = []
             for j, r in zip(idx, ref):
                 g = out[j].cpu().numpy().T  # [w][h] -> h x w
