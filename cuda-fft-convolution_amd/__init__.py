@@ -252,15 +252,26 @@ class Plan:
         _check(self._lib.fftconv_plan_mark_spectrum_valid(self._h))
 
     # -- convolution
-    def convolve(self, kernelCell):
-        """host kernels (list of kh x kw x F float32) -> list of host maps"""
+    def convolve(self, kernelCell, out=None):
+        """host kernels (list of kh x kw x F float32) -> list of host maps.  ``out``: optional list
+        of caller buffers to fill (FFT_H x FFT_W float32, Fortran order; pageable, or pinned for a
+        direct DMA copy-out) instead of fresh arrays."""
         ks, kptr, kh, kw, kf = _kernel_tables(kernelCell)
         for k in ks:
             if k.shape[2] != self.info.feature_dim:  # src/cudaConvolutionFFT.cu:242
                 raise FFTConvError(-3, "Kernel and Data must have the same number of features and kernel "
                                        "size should be smaller than data size")
         n = len(ks)
-        outs = [np.empty((self.info.fft_h, self.info.fft_w), dtype=np.float32, order="F") for _ in range(n)]
+        if out is None:
+            outs = [np.empty((self.info.fft_h, self.info.fft_w), dtype=np.float32, order="F") for _ in range(n)]
+        else:
+            outs = list(out)
+            if len(outs) != n:
+                raise FFTConvError(-1, "out must hold one buffer per kernel")
+            for o in outs:
+                if (o.dtype != np.float32 or o.shape != (self.info.fft_h, self.info.fft_w)
+                        or not o.flags.f_contiguous or not o.flags.writeable):
+                    raise FFTConvError(-1, "out buffers must be writable FFT_H x FFT_W float32 in Fortran order")
         optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
         _check(self._lib.fftconv_plan_convolve(self._h, n, kptr, kh, kw, HOST, optr, HOST))
         return outs

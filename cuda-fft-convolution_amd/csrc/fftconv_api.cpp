@@ -2,13 +2,18 @@
 // HIP kernels.  C++ host code in the role of the reference's MEX gateways
 // (src/cudaConvolutionFFT.cu, src/cudaFFTData.cu, src/cudaConvFFTData.cu); no CPU compute path.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fftconv.h"
@@ -72,6 +77,142 @@ struct DevBuf {
     size_t bytes() const { return cap * sizeof(T); }
 };
 
+// Host-output streaming (the reference's blocking pageable cudaMemcpy of every
+// map, src/cudaConvolutionFFT.cu:284-286, and the async intent of
+// src/cudaConvFFTDataStreams.cu:368-369,429-430): finished maps leave the device while the next
+// batch is computed.  Two ways out, both driven by a few host threads of the plan:
+//   direct (default)  each thread copies whole maps from the device staging buffer straight into
+//                     the caller's memory on a stream of its own (the HIP runtime pins pageable
+//                     pages in place: measured 51 GB/s on MI355X, the PCIe rate);
+//   ring              the maps travel through a ring of pinned chunks on one copy stream and the
+//                     threads move the landed chunks into the caller's buffers (buffers the
+//                     caller pinned itself are written directly by the DMA engine).
+struct HostRing {
+    int gpu_id = 0;
+    size_t chunk_bytes = 0;
+    int nslots = 0;
+    char* base = nullptr;              // hipHostMalloc: nslots * chunk_bytes
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> landed;    // per slot: its D2H copy has finished
+    hipEvent_t compute_done[2] = {nullptr, nullptr};  // per device staging buffer
+    hipEvent_t copy_done[2] = {nullptr, nullptr};
+    struct Task { int slot; char* dst; size_t bytes; const char* src; int buf; };  // slot < 0: direct copy from src
+    std::deque<Task> q;
+    std::mutex m;
+    std::condition_variable cv_task, cv_slot;
+    std::vector<char> busy;            // slot claimed (from acquire until its host copy is done)
+    int next_slot = 0;
+    int open_tasks = 0;
+    int open_direct[2] = {0, 0};       // direct copies still reading device staging buffer 0 / 1
+    bool stop = false;
+    hipError_t worker_error = hipSuccess;
+    std::vector<std::thread> workers;
+
+    // Fresh caller buffers (malloc'ed, never touched) would be faulted in page by page inside the
+    // runtime's pinning of the destination; populating them here, in the copy threads and ahead
+    // of the DMA, costs nothing for resident pages and is several times faster for new ones.
+    static void prefault(char* dst, size_t bytes) {
+#ifdef MADV_POPULATE_WRITE
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + 4095) & ~(uintptr_t)4095;
+        const uintptr_t b = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(uintptr_t)4095;
+        if (b > a) {
+            (void)madvise(reinterpret_cast<void*>(a), b - a, MADV_POPULATE_WRITE);
+        }
+#else
+        (void)dst; (void)bytes;
+#endif
+    }
+    void work() {
+        (void)hipSetDevice(gpu_id);
+        hipStream_t own = nullptr;
+        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = copy_stream;
+        work_loop(own);
+        if (own != copy_stream) (void)hipStreamDestroy(own);
+    }
+    void work_loop(hipStream_t own) {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_task.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                t = q.front();
+                q.pop_front();
+            }
+            hipError_t e;
+            if (t.slot < 0) {
+                prefault(t.dst, t.bytes);
+                e = hipStreamWaitEvent(own, compute_done[t.buf], 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(t.dst, t.src, t.bytes, hipMemcpyDeviceToHost, own);
+                if (e == hipSuccess) e = hipStreamSynchronize(own);
+            } else {
+                e = hipEventSynchronize(landed[t.slot]);
+                if (e == hipSuccess) memcpy(t.dst, base + (size_t)t.slot * chunk_bytes, t.bytes);
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (e != hipSuccess && worker_error == hipSuccess) worker_error = e;
+                if (t.slot < 0) open_direct[t.buf]--; else busy[t.slot] = 0;
+                open_tasks--;
+            }
+            cv_slot.notify_all();
+        }
+    }
+    int acquire() {  // next slot in ring order, once its previous contents have been copied out
+        std::unique_lock<std::mutex> lk(m);
+        const int s = next_slot;
+        cv_slot.wait(lk, [&] { return !busy[s]; });
+        busy[s] = 1;
+        next_slot = (s + 1) % nslots;
+        return s;
+    }
+    void unclaim(int s) {
+        { std::lock_guard<std::mutex> lk(m); busy[s] = 0; }
+        cv_slot.notify_all();
+    }
+    void submit(int slot, char* dst, size_t bytes) {
+        { std::lock_guard<std::mutex> lk(m); q.push_back(Task{slot, dst, bytes, nullptr, 0}); open_tasks++; }
+        cv_task.notify_one();
+    }
+    void submit_direct(const char* src, char* dst, size_t bytes, int buf) {
+        { std::lock_guard<std::mutex> lk(m); q.push_back(Task{-1, dst, bytes, src, buf}); open_tasks++; open_direct[buf]++; }
+        cv_task.notify_one();
+    }
+    // the direct copies out of staging buffer `buf` have finished: it may be overwritten
+    void wait_staging_free(int buf) {
+        std::unique_lock<std::mutex> lk(m);
+        cv_slot.wait(lk, [&] { return open_direct[buf] == 0; });
+    }
+    // every queued chunk has reached the caller's memory (also drains the copy stream)
+    hipError_t wait_idle() {
+        hipError_t e = hipStreamSynchronize(copy_stream);
+        std::unique_lock<std::mutex> lk(m);
+        cv_slot.wait(lk, [&] { return open_tasks == 0; });
+        if (e == hipSuccess) e = worker_error;
+        worker_error = hipSuccess;
+        return e;
+    }
+    void shutdown() {
+        if (!workers.empty()) {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            cv_task.notify_all();
+            for (std::thread& t : workers) t.join();
+            workers.clear();
+        }
+        for (hipEvent_t e : landed) (void)hipEventDestroy(e);
+        landed.clear();
+        for (int i = 0; i < 2; i++) {
+            if (compute_done[i]) (void)hipEventDestroy(compute_done[i]);
+            if (copy_done[i]) (void)hipEventDestroy(copy_done[i]);
+            compute_done[i] = copy_done[i] = nullptr;
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        copy_stream = nullptr;
+        if (base) (void)hipHostFree(base);
+        base = nullptr;
+    }
+};
+
 int cols_threads(const Geometry& g) {
     long work = (long)g.T_cols * g.M;
     if (work >= 4096) return 512;
@@ -115,6 +256,11 @@ struct fftconv_plan {
     DevBuf<int> cw_tile_row_of;
     int num_cus = 256;
     long opt_batch_maps = 0;
+    long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
+    long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
+    long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
+    long opt_host_slots = 0;       // ring chunks (0 = auto)
+    HostRing* ring = nullptr;      // created on the first host-output convolve
     bool profile = false;
     // kernel column spectra of the first chunk already in A (fftconv_plan_prepare_kernels_packed)
     struct { const float* dk = nullptr; int n = 0, kh = 0, kw = 0; } prepared;
@@ -161,7 +307,15 @@ struct fftconv_plan {
         pending.clear();
         return 0;
     }
+    void release_ring() {
+        if (ring) {
+            ring->shutdown();
+            delete ring;
+            ring = nullptr;
+        }
+    }
     void release_all() {
+        release_ring();
         for (EventPair& ep : pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
         for (EventPair& ep : pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
         pending.clear();
@@ -229,6 +383,92 @@ int check_kernel_size(const fftconv_plan* p, int kh, int kw) {
     return 0;
 }
 
+// pinned ring + copy stream + host copy threads of the host-output path, sized for this plan's maps
+int ring_ensure(fftconv_plan* p) {
+    if (p->ring) return 0;
+    const size_t map_bytes = p->g.map_elems() * sizeof(float);
+    size_t chunk = p->opt_host_chunk_kb > 0 ? (size_t)p->opt_host_chunk_kb << 10 : (size_t)8 << 20;
+    chunk = std::min(chunk, (map_bytes + 4095) / 4096 * 4096);
+    chunk = std::max<size_t>(4096, chunk / 4096 * 4096);
+    const bool use_ring = p->opt_host_stream == 2;
+    int nthreads = p->opt_host_threads > 0 ? (int)p->opt_host_threads
+                   : (int)std::max(1u, std::min(use_ring ? 6u : 4u, std::thread::hardware_concurrency() / 2));
+    int nslots = !use_ring ? 0 : p->opt_host_slots > 0 ? (int)p->opt_host_slots : std::max(8, 2 * nthreads + 2);
+    HostRing* r = new (std::nothrow) HostRing();
+    if (!r) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
+    r->gpu_id = p->gpu_id;
+    r->chunk_bytes = chunk;
+    r->nslots = nslots;
+    r->busy.assign(nslots, 0);
+    hipError_t e = hipSuccess;
+    if (nslots > 0) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&r->base), chunk * nslots, hipHostMallocDefault);
+        if (e != hipSuccess) r->base = nullptr;
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&r->compute_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r->copy_done[i], hipEventDisableTiming);
+    }
+    for (int i = 0; i < nslots && e == hipSuccess; i++) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventBlockingSync);
+        if (e == hipSuccess) r->landed.push_back(ev);
+    }
+    if (e != hipSuccess) {
+        r->shutdown();
+        delete r;
+        return fail(FFTCONV_ERR_HIP, "host-output ring setup failed: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < nthreads; i++) r->workers.emplace_back([r] { r->work(); });
+    p->ring = r;
+    return 0;
+}
+
+bool caller_pinned(const void* ptr) {
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // pageable memory is reported as an error: not one
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// queue the copy-out of the maps [first, first + count) that sit in staging buffer `buf`
+int ring_drain(fftconv_plan* p, const Sink& sink, int first, int count, int buf, const float* staging) {
+    HostRing* r = p->ring;
+    const size_t map_bytes = p->g.map_elems() * sizeof(float);
+    if (r->nslots == 0) {   // direct: whole maps, one per host thread at a time
+        for (int j = 0; j < count; j++)
+            r->submit_direct(reinterpret_cast<const char*>(staging + (size_t)j * p->g.map_elems()),
+                             reinterpret_cast<char*>(sink.ptrs[first + j]), map_bytes, buf);
+        return 0;
+    }
+    HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->compute_done[buf], 0));
+    for (int j = 0; j < count; j++) {
+        char* dst = reinterpret_cast<char*>(sink.ptrs[first + j]);
+        const char* src = reinterpret_cast<const char*>(staging + (size_t)j * p->g.map_elems());
+        if (caller_pinned(dst)) {
+            HIP_TRY(hipMemcpyAsync(dst, src, map_bytes, hipMemcpyDeviceToHost, r->copy_stream));
+            continue;
+        }
+        for (size_t off = 0; off < map_bytes; off += r->chunk_bytes) {
+            const size_t n = std::min(r->chunk_bytes, map_bytes - off);
+            const int s = r->acquire();
+            hipError_t e = hipMemcpyAsync(r->base + (size_t)s * r->chunk_bytes, src + off, n, hipMemcpyDeviceToHost, r->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(r->landed[s], r->copy_stream);
+            if (e != hipSuccess) {
+                r->unclaim(s);
+                return fail(FFTCONV_ERR_HIP, "device-to-host copy failed: %s", hipGetErrorString(e));
+            }
+            r->submit(s, dst + off, n);
+        }
+    }
+    HIP_TRY(hipEventRecord(r->copy_done[buf], r->copy_stream));
+    return 0;
+}
+
 // h-transform of the kernels [a0, a0 + na) of a packed group into the column-spectrum buffer A
 int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh, int kw) {
     const Geometry& g = p->g;
@@ -246,7 +486,7 @@ int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh,
 
 // Core of the per-kernel loop (src/cudaConvolutionFFT.cu:204-291) for n kernels of one size,
 // packed on the device at dk ([n][F][kw][kh]).
-int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
+int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
     const Geometry& g = p->g;
     if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
     if (int rc = check_kernel_size(p, kh, kw)) return rc;
@@ -256,8 +496,14 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
     const bool staged = (sink.packed == nullptr);
+    // host output: two staging buffers, the copy-out of batch b overlaps the compute of batch b + 1
+    const bool streamed = staged && sink.location == FFTCONV_HOST && p->opt_host_stream != 0;
     if (staged)
-        if (int rc = p->O.ensure(g.map_elems() * nbY)) return rc;
+        if (int rc = p->O.ensure(g.map_elems() * nbY * (streamed ? 2 : 1))) return rc;
+    if (streamed)
+        if (int rc = ring_ensure(p)) return rc;
+    int batch = 0;
+    struct { bool valid = false; int first = 0, count = 0, buf = 0; } prev;
 
     const int T = g.T_cols;
     const int cthreads = cols_threads(g), rthreads = rows_threads(g);
@@ -281,7 +527,12 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
                 HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
             }
             if (int rc = p->prof_end()) return rc;
-            float* obase = staged ? p->O.p : sink.packed + (size_t)(a0 + y0) * g.map_elems();
+            const int buf = streamed ? (batch & 1) : 0;
+            float* obase = staged ? p->O.p + (size_t)buf * nbY * g.map_elems() : sink.packed + (size_t)(a0 + y0) * g.map_elems();
+            if (streamed && batch >= 2) {   // staging buffer `buf` still holds batch - 2 until its copy-out is over
+                if (p->ring->nslots == 0) p->ring->wait_staging_free(buf);
+                else HIP_TRY(hipStreamWaitEvent(p->stream, p->ring->copy_done[buf], 0));
+            }
             if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
             if (g.use_wide()) {
                 FastColsWideArgs fa = fast_cols_wide_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
@@ -294,7 +545,13 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
                 HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));
             }
             if (int rc = p->prof_end()) return rc;
-            if (staged) {
+            if (streamed) {
+                HIP_TRY(hipEventRecord(p->ring->compute_done[buf], p->stream));
+                if (prev.valid)
+                    if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, p->O.p + (size_t)prev.buf * nbY * g.map_elems())) return rc;
+                prev.valid = true; prev.first = a0 + y0; prev.count = ny; prev.buf = buf;
+                batch++;
+            } else if (staged) {
                 for (int j = 0; j < ny; j++) {
                     float* dst = sink.ptrs[a0 + y0 + j];
                     HIP_TRY(hipMemcpyAsync(dst, p->O.p + (size_t)j * g.map_elems(), g.map_elems() * sizeof(float),
@@ -305,7 +562,25 @@ int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sin
             }
         }
     }
+    if (streamed) {
+        if (prev.valid)
+            if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, p->O.p + (size_t)prev.buf * nbY * g.map_elems())) return rc;
+        hipError_t e = p->ring->wait_idle();
+        if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "host-output copy failed: %s", hipGetErrorString(e));
+    }
     return 0;
+}
+
+// run_group_impl + on failure: nothing of the host-output ring may still be writing into the
+// caller's buffers when the error is returned
+int run_group(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
+    const int rc = run_group_impl(p, n, dk, kh, kw, sink);
+    if (rc && p->ring) {
+        const std::string keep = g_last_error;
+        (void)p->ring->wait_idle();
+        g_last_error = keep;
+    }
+    return rc;
 }
 
 int check_thread_size(const double* thread_size, int n_thread_size) {
@@ -618,6 +893,16 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "host_stream") || !strcmp(name, "host_threads") || !strcmp(name, "host_chunk_kb") || !strcmp(name, "host_slots")) {
+        if (value < 0 || value > (1 << 20)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);
+        if (int rc = use_device(plan)) return rc;
+        HIP_TRY(hipStreamSynchronize(plan->stream));
+        plan->release_ring();      // rebuilt with the new shape by the next host-output call
+        if (!strcmp(name, "host_stream") && value > 2) return fail(FFTCONV_ERR_INVALID_ARG, "host_stream is 0, 1 or 2");
+        (!strcmp(name, "host_stream") ? plan->opt_host_stream : name[5] == 't' ? plan->opt_host_threads
+         : name[5] == 'c' ? plan->opt_host_chunk_kb : plan->opt_host_slots) = value;
+        return 0;
+    }
     return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

@@ -166,7 +166,12 @@ int fftconv_plan_prepare_kernels_packed(fftconv_plan *plan, int n_kernel, const 
 int fftconv_plan_synchronize(fftconv_plan *plan);
 
 /* Options: "batch_maps" (kernels per spectral/output launch, 0 = auto),
- *          "profile" (1: time every kernel launch with HIP events on the plan's stream). */
+ *          "profile" (1: time every kernel launch with HIP events on the plan's stream),
+ *          "host_stream" (how maps reach HOST output buffers -- the reference's blocking
+ *             cudaMemcpy per map, src/cudaConvolutionFFT.cu:284-286: 0 = blocking copies after each
+ *             batch; 1 (default) = host threads of the plan copy batch b straight into the caller's
+ *             buffers while batch b+1 is computed; 2 = through a ring of pinned chunks),
+ *          "host_threads", "host_chunk_kb", "host_slots" (shape of that machinery, 0 = auto). */
 int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
 
 typedef struct fftconv_profile {

@@ -283,3 +283,72 @@ def test_cfg4_and_cfg5_geometry_vs_oracle(fc, oracle):
         got = fc.cudaConvolutionFFT(img, kh, kw, ks)
         ref = oracle.conv_fft(img, kh, kw, ks)
         assert util.rel_err(got[0], ref[0]) < TOL
+
+
+# ---- host-output streaming (pinned ring, copy stream, host copy threads) --------------------------
+
+@pytest.mark.parametrize("ring", [
+    {},                                                                      # default: direct copies by 2 host threads
+    {"host_stream": 1, "host_threads": 3},
+    {"host_stream": 1, "host_threads": 1},
+    {"host_stream": 2},                                                      # pinned ring, default shape
+    {"host_stream": 2, "host_chunk_kb": 4, "host_slots": 3, "host_threads": 2},   # many wraps of a tiny ring
+    {"host_stream": 2, "host_chunk_kb": 64, "host_slots": 2, "host_threads": 1},
+    {"host_stream": 0},                                                      # blocking copy-out
+])
+def test_host_output_streaming_matches_oracle(fc, oracle, ring):
+    """More batches than staging buffers (batch_maps = 2, 9 kernels in ragged groups): every
+    map must arrive complete and in its own buffer whatever the ring shape."""
+    rng = np.random.default_rng(77)
+    H, W, F, kh, kw = 120, 70, 2, 9, 6
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(7)]
+    ks += [rng.random((kh - 3, kw - 1, F), dtype=np.float32) for _ in range(2)]
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    with fc.Plan(H, W, F, kh, kw) as plan:
+        plan.set_option("batch_maps", 2)
+        for k, v in ring.items():
+            plan.set_option(k, v)
+        plan.set_image(data)
+        for rep in range(2):         # second call reuses ring and staging
+            got = plan.convolve(ks)
+            for g, r in zip(got, ref):
+                assert util.rel_err(g, r) < TIGHT
+        # caller buffers, pre-filled with garbage
+        bufs = [np.full(ref[0].shape, np.nan, dtype=np.float32, order="F") for _ in ks]
+        plan.convolve(ks, out=bufs)
+        for g, r in zip(bufs, ref):
+            assert util.rel_err(g, r) < TIGHT
+
+
+def test_host_output_into_pinned_buffers(fc, oracle):
+    """Buffers the caller pinned itself: plain DMA in the direct mode, no ring hop in the ring mode."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(78)
+    H, W, kh, kw = 200, 90, 11, 7
+    data = rng.random((H, W, 1), dtype=np.float32)
+    ks = [rng.random((kh, kw, 1), dtype=np.float32) for _ in range(5)]
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    fh, fw = ref[0].shape
+    pinned = [torch.full((fw, fh), float("nan"), dtype=torch.float32).pin_memory() for _ in ks]
+    bufs = [t.numpy().T for t in pinned]            # FFT_H x FFT_W Fortran-order views
+    assert all(b.flags.f_contiguous for b in bufs)
+    with fc.Plan(H, W, 1, kh, kw) as plan:
+        plan.set_option("batch_maps", 2)
+        plan.set_image(data)
+        for mode in (1, 2):
+            for b in bufs:
+                b.fill(np.nan)
+            plan.set_option("host_stream", mode)
+            plan.convolve(ks, out=bufs)
+            for g, r in zip(bufs, ref):
+                assert util.rel_err(g, r) < TIGHT
+
+
+def test_host_output_streaming_large_maps(fc, oracle):
+    """cfg2-sized maps (4.7 MB each, several ring chunks per map) through the one-shot entry."""
+    img, ks = util.synth(2, 1024, 1024, 1, 63, 63, 5)
+    got = fc.cudaConvolutionFFT(img, 63, 63, ks)
+    ref = oracle.conv_fft(img, 63, 63, ks)
+    for g, r in zip(got, ref):
+        assert util.rel_err(g, r) < TOL
