@@ -11,6 +11,7 @@
 #include "fast_cols_fwd.hpp"
 #include "fast_cols_wide.hpp"
 #include "fast_rows.hpp"
+#include "fast_rows_multi.hpp"
 #include "fast_rows_pair.hpp"
 #include "planner.hpp"
 

@@ -1,0 +1,199 @@
+// fast_rows_multi.hpp -- spectral-row kernel, several maps per workgroup (F = 1).
+//
+// fast_rows_body (fast_rows.hpp) gives every (row group, kernel) pair a workgroup of its own:
+// each one pays the launch, the stage-2 twiddle fill, the exposed latency of its kernel-row load
+// and a fresh fetch of the image-spectrum row, and it retires only after its stores have
+// drained.  Here a workgroup keeps its image-spectrum row IN REGISTERS and walks G consecutive
+// kernels with it:
+//   * the image-spectrum row is fetched once per G maps instead of once per map (the largest
+//     read of this kernel: 8*C bytes per map -> 8*C/G);
+//   * the next kernel's row (kw complex values: one or two registers per thread) is prefetched
+//     right after stage 1 has consumed the current one, so its latency hides behind four phases;
+//   * the stores of map m drain while map m + 1 is transformed.
+// The phases are those of fast_rows_body, unchanged; P5 ends with a barrier because the next
+// map's P1 overwrites the LDS row.
+#pragma once
+#include "fast_rows.hpp"
+
+namespace fc {
+
+template <class C, int NZ2, class Ctx>
+FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, int kernel0, int nk, int rows) {
+    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
+    using State = RowState<C, false>;
+    c32* tw2 = lds + RPW * L;
+    const int kw = g.kw;
+    const int row0 = group * RPW;
+    const bool tiled = g.y_row_of != nullptr;
+
+    auto load_x = [&](int t, State& st, int kernel) {
+        const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride;
+        static_for<0, C::RND1>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            const int u = t + NT * r;
+            const int rr = u / C::NB1, j = u - rr * C::NB1;
+            const int row = row0 + rr;
+            st.x[r] = (rr < RPW && row < rows && j < kw) ? abase[(size_t)row * g.a_pitch + j] : mk(0.f, 0.f);
+        });
+    };
+
+    // once per workgroup: stage-2 twiddles into LDS, first kernel row, image-spectrum row
+    ctx.phase_nosync([&](int t, State& st) {
+        for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
+        load_x(t, st, kernel0);
+        const int rr = t / C::NB3, q = t - rr * C::NB3;
+        if (rr < RPW && row0 + rr < rows) {
+            const c32* srow = g.S + (size_t)(row0 + rr) * g.s_pitch;
+            static_for<0, R3 / 2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
+                st.s[2 * h] = v.a;
+                st.s[2 * h + 1] = v.b;
+            });
+        } else {
+            static_for<0, R3>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
+        }
+    });
+
+    for (int m = 0; m < nk; m++) {
+        const int kernel = kernel0 + m;
+
+        // P1: forward stage 1, pruned (one non-zero input per butterfly)
+        ctx.phase([&](int t, State& st) {
+            static_for<0, C::RND1>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int u = t + NT * r;
+                const int rr = u / C::NB1, j = u - rr * C::NB1;
+                if (rr < RPW && j < kw) {
+                    c32* buf = lds + rr * L;
+                    c32 p[R1];
+                    int jj = j;
+                    FC_OPAQUE(jj);   // the twiddle chain is recomputed per map, not kept across the loop
+                    power_chain<R1>(g.tw1[jj], p);
+                    buf[j] = st.x[r];
+                    static_for<1, R1>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        buf[c * m1 + j] = cmul(st.x[r], p[c]);
+                    });
+                }
+            });
+        });
+
+        // the next kernel's row flies during P2..P5
+        if (m + 1 < nk) ctx.phase_nosync([&](int t, State& st) { load_x(t, st, kernel + 1); });
+
+        // P2: forward stage 2
+        ctx.phase([&](int t, State&) {
+            static_for<0, C::RND2>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int u = t + NT * r;
+                const int rr = u / C::NB2, w = u - rr * C::NB2;
+                if (rr < RPW) {
+                    const int c1 = w / R3, b = w - c1 * R3;
+                    c32* p = lds + rr * L + c1 * m1 + b;
+                    c32 v[R2];
+                    static_for<0, R2>([&](auto a_) {
+                        constexpr int a = decltype(a_)::value;
+                        if constexpr (a < NZ2) v[a] = (a * R3 + b < kw) ? p[a * R3] : mk(0.f, 0.f);
+                        else v[a] = mk(0.f, 0.f);
+                    });
+                    Dft<R2, -1>::run(v);
+                    p[0] = v[0];
+                    static_for<1, R2>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        p[c * R3] = cmul(v[c], tw2[(c - 1) * R3 + b]);
+                    });
+                }
+            });
+        });
+
+        // P3: forward stage 3, product with the image spectrum (registers), inverse stage 3
+        ctx.phase([&](int t, State& st) {
+            const int rr = t / C::NB3, q = t - rr * C::NB3;
+            if (rr < RPW) {
+                c32* p = lds + rr * L + q * R3;
+                c32 v[R3];
+                static_for<0, R3 / 2>([&](auto h_) {
+                    constexpr int h = decltype(h_)::value;
+                    c32x2 w = *reinterpret_cast<const c32x2*>(p + 2 * h);
+                    v[2 * h] = w.a;
+                    v[2 * h + 1] = w.b;
+                });
+                Dft<R3, -1>::run(v);
+                static_for<0, R3>([&](auto a_) {
+                    constexpr int a = decltype(a_)::value;
+                    v[a] = cmul(v[a], st.s[a]);
+                });
+                Dft<R3, +1>::run(v);
+                static_for<0, R3 / 2>([&](auto h_) {
+                    constexpr int h = decltype(h_)::value;
+                    c32x2 w;
+                    w.a = v[2 * h];
+                    w.b = v[2 * h + 1];
+                    *reinterpret_cast<c32x2*>(p + 2 * h) = w;
+                });
+            }
+        });
+
+        // P4: inverse stage 2
+        ctx.phase([&](int t, State&) {
+            static_for<0, C::RND2>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int u = t + NT * r;
+                const int rr = u / C::NB2, w = u - rr * C::NB2;
+                if (rr < RPW) {
+                    const int c1 = w / R3, b = w - c1 * R3;
+                    c32* p = lds + rr * L + c1 * m1 + b;
+                    c32 v[R2];
+                    v[0] = p[0];
+                    static_for<1, R2>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        v[c] = cmulc(p[c * R3], tw2[(c - 1) * R3 + b]);
+                    });
+                    Dft<R2, +1>::run(v);
+                    static_for<0, R2>([&](auto a_) {
+                        constexpr int a = decltype(a_)::value;
+                        p[a * R3] = v[a];
+                    });
+                }
+            });
+        });
+
+        // P5: inverse stage 1 straight to global memory; the barrier protects the LDS row
+        // against the next map's P1
+        c32* ybase = g.Y + (size_t)kernel * g.y_kernel_stride;
+        ctx.phase([&](int t, State&) {
+            static_for<0, C::RND1>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                int u = t + NT * r;
+                FC_OPAQUE(u);   // twiddle chains and store offsets are recomputed per map, not kept (spilled) across the loop
+                const int rr = u / C::NB1, j = u - rr * C::NB1;
+                const int row = row0 + rr;
+                if (rr < RPW && row < rows) {
+                    const c32* buf = lds + rr * L;
+                    c32 p[R1];
+                    power_chain<R1>(g.tw1[j], p);
+                    c32 v[R1];
+                    v[0] = buf[j];
+                    static_for<1, R1>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        v[c] = cmulc(buf[c * m1 + j], p[c]);
+                    });
+                    Dft<R1, +1>::run(v);
+                    c32* yrow = ybase + (tiled ? ((size_t)g.y_row_of[row] << g.y_tile_shift) : (size_t)row * g.y_pitch);
+                    static_for<0, R1>([&](auto a_) {
+                        constexpr int a = decltype(a_)::value;
+                        int w = j + a * m1;
+                        if (w < g.wout) {
+                            if (tiled) FC_STREAM_STORE(&yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))], v[a]);
+                            else FC_STREAM_STORE(&yrow[w], v[a]);
+                        }
+                    });
+                }
+                FC_SCHED_FENCE();
+            });
+        });
+    }
+}
+
+}  // namespace fc

@@ -73,6 +73,15 @@
 #define FC_SCHED_FENCE() ((void)0)
 #endif
 
+// Makes a lane-varying integer opaque to the optimiser at this point (device only): what is computed
+// from it inside a loop is not loop-invariant any more, so it is recomputed per iteration
+// instead of being hoisted and kept in registers across the whole loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FC_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define FC_OPAQUE(x) ((void)0)
+#endif
+
 namespace fc {
 
 struct alignas(8) c32 {

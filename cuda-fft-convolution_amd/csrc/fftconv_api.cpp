@@ -519,6 +519,9 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
             if (g.y_pre()) {
                 FastRowsPairArgs fa = fast_rows_pair_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_fast_rows_pair(g.Lw, fast_rows_nz2(g, kw), fa, g.M / 2 + 1, ny, p->stream));
+            } else if (g.rows_multi()) {
+                FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
+                HIP_TRY(launch_fast_rows_multi(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_group, p->stream));
             } else if (g.fast_rows.ok) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_persistent ? 4 * p->num_cus : 0, g.rows_wg_order, p->stream));

@@ -121,6 +121,33 @@ __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_persist(FastRowsArgs a
     fast_rows_persist_body<Cfg, NZ2, MULTIF>(ctx, reinterpret_cast<c32*>(fc_smem), a, rows, item0, item1);
 }
 
+template <class Cfg, int NZ2>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_multi(FastRowsArgs a, int rows, int kernels, int per_wg) {
+    const int group = (int)blockIdx.x;
+    const int kernel0 = (int)blockIdx.y * per_wg;
+    const int nk = kernels - kernel0 < per_wg ? kernels - kernel0 : per_wg;
+    DevPhaseCtx<RowState<Cfg, false>> ctx;
+    fast_rows_multi_body<Cfg, NZ2>(ctx, reinterpret_cast<c32*>(fc_smem), a, group, kernel0, nk, rows);
+}
+
+struct FastRowsMultiLauncher {
+    const FastRowsArgs& a;
+    int rows, kernels, per_wg;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg, int NZ2>
+    void go() {
+        static unsigned long long attr_mask = 0;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        err = ensure_lds_attr(k_fast_rows_multi<Cfg, NZ2>, attr_mask);
+        if (err != hipSuccess) return;
+        const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
+        const dim3 grid(groups, (kernels + per_wg - 1) / per_wg);
+        hipLaunchKernelGGL((k_fast_rows_multi<Cfg, NZ2>), grid, dim3(Cfg::NT), lds, s, a, rows, kernels, per_wg);
+        err = hipGetLastError();
+    }
+};
+
 template <class Cfg, int MODE>
 __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols(FastColsArgs a) {
     DevPhaseCtx<std::conditional_t<MODE == 3, ColPairState<Cfg>, ColState<Cfg>>> ctx;
@@ -307,6 +334,14 @@ struct FastRowsLauncher {
 hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int persist_wgs, int order, hipStream_t s) {
     if (rows <= 0 || kernels <= 0) return hipSuccess;
     FastRowsLauncher l{a, rows, kernels, s, persist_wgs, order};
+    if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s) {
+    if (rows <= 0 || kernels <= 0) return hipSuccess;
+    if (a.F != 1 || kernels_per_wg < 1) return hipErrorInvalidValue;
+    FastRowsMultiLauncher l{a, rows, kernels, kernels_per_wg, s};
     if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
     return l.err;
 }

@@ -54,6 +54,8 @@ struct Geometry {
     int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
     int y_row_order = 0;       // see make_fast_cols_tables
     int rows_wg_order = 0;     // workgroup order of the fast row kernel (kernels.hip: k_fast_rows); 1, 2 measured equal
+    int rows_group = 0;        // > 1: maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1)
+    bool rows_multi() const { return rows_group > 1 && F == 1 && fast_rows.ok && !y_pre() && !rows_persistent; }
     bool rows_persistent = false; // persistent variant of the fast single-row kernel (measured slower: kept for A/B)
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
@@ -82,6 +84,7 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e);
     if (const char* e = getenv("FFTCONV_ROWS_PERSIST")) g.rows_persistent = atoi(e) != 0;
     if (const char* e = getenv("FFTCONV_ROWS_ORDER")) g.rows_wg_order = atoi(e);
+    if (const char* e = getenv("FFTCONV_ROWS_GROUP")) g.rows_group = atoi(e);
     if (const char* e = getenv("FFTCONV_PAIR_ROWS")) g.pair_rows_on = atoi(e) != 0;
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;

@@ -51,8 +51,22 @@ struct EmuFastRows {
     c32* lds;
     int rows;
     bool persist;
+    int group = 0;   // > 1: multi-map body; the emulator holds one kernel at a time, so the walk
+                     // over `group` maps is emulated with the same kernel (strides 0): the loop,
+                     // the prefetch slot and the LDS reuse are exercised, the indexing is not
     template <class Cfg, int NZ2>
     void go() {
+        if (group > 1 && a.F == 1) {
+            FastRowsArgs b = a;
+            b.a_kernel_stride = 0;
+            b.y_kernel_stride = 0;
+            for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
+                for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+                HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
+                fast_rows_multi_body<Cfg, NZ2>(ctx, lds, b, grp, 0, group, rows);
+            }
+            return;
+        }
         if constexpr (Cfg::RPW == 1)
         if (persist) {   // 5 persistent workgroups share the rows (uneven split on purpose)
             const int nwg = 5, total = rows;
@@ -248,7 +262,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fr_tw1 = t.fr.tw1.data();
             d.fr_tw2 = t.fr.tw2.data();
             FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
-            EmuFastRows run{fa, lds.data(), g.rows, g.rows_persistent};
+            EmuFastRows run{fa, lds.data(), g.rows, g.rows_persistent, g.rows_multi() ? g.rows_group : 0};
             if (!fast_rows_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
         } else {
             SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
