@@ -16,6 +16,17 @@ FC_HD c32 mul_j(c32 a) {
     if constexpr (SGN > 0) return mk(-a.y, a.x);
     else return mk(a.y, -a.x);
 }
+// a + (SGN*i)*b, a - (SGN*i)*b: one packed add each
+template <int SGN>
+FC_HD c32 add_j(c32 a, c32 b) {
+    if constexpr (SGN > 0) return add_jb(a, b);
+    else return sub_jb(a, b);
+}
+template <int SGN>
+FC_HD c32 sub_j(c32 a, c32 b) {
+    if constexpr (SGN > 0) return sub_jb(a, b);
+    else return add_jb(a, b);
+}
 
 // a * exp(SGN*2*pi*i*K/R), K and R compile-time.
 template <int R, int K, int SGN>
@@ -35,11 +46,14 @@ FC_HD c32 mul_root(c32 a) {
         constexpr float h = 0.70710678118654752f;
         constexpr float sc = (q == 1 || q == 7) ? 1.f : -1.f;
         constexpr float ss = ((q == 1 || q == 3) ? 1.f : -1.f) * (SGN > 0 ? 1.f : -1.f);
-        return mk((sc * a.x - ss * a.y) * h, (ss * a.x + sc * a.y) * h);
+        // (sc*a + i*ss*a) * h
+        c32 t = (ss * sc > 0.f) ? add_jb(a, a) : sub_jb(a, a);
+        return scale(t, sc * h);
     } else {
         constexpr float c = Roots<R>::c[k];
         constexpr float s = (SGN > 0 ? 1.f : -1.f) * Roots<R>::s[k];
-        return mk(a.x * c - a.y * s, a.x * s + a.y * c);
+        // a*c + i*s*a
+        return fma_js(s, a, scale(a, c));
     }
 }
 
@@ -73,11 +87,11 @@ template <int SGN>
 struct Dft<4, SGN, void> {
     static FC_HD void run(c32 (&v)[4]) {
         c32 s0 = v[0] + v[2], s1 = v[0] - v[2];
-        c32 s2 = v[1] + v[3], s3 = mul_j<SGN>(v[1] - v[3]);
+        c32 s2 = v[1] + v[3], d = v[1] - v[3];
         v[0] = s0 + s2;
-        v[1] = s1 + s3;
+        v[1] = add_j<SGN>(s1, d);
         v[2] = s0 - s2;
-        v[3] = s1 - s3;
+        v[3] = sub_j<SGN>(s1, d);
     }
 };
 
@@ -105,14 +119,12 @@ struct DftOddPrime {
                 constexpr int idx = (m * (k + 1)) % P;
                 constexpr float c = Roots<P>::c[idx];
                 constexpr float sn = Roots<P>::s[idx];
-                A.x += c * s[k].x;
-                A.y += c * s[k].y;
-                B.x += sn * d[k].x;
-                B.y += sn * d[k].y;
+                A = fma_real(c, s[k], A);
+                if constexpr (k == 0) B = scale(d[k], sn);
+                else B = fma_real(sn, d[k], B);
             });
-            c32 jB = mul_j<SGN>(B);
-            v[m] = A + jB;
-            v[P - m] = A - jB;
+            v[m] = add_j<SGN>(A, B);
+            v[P - m] = sub_j<SGN>(A, B);
         });
     }
 };

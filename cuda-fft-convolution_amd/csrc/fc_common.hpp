@@ -84,18 +84,112 @@
 
 namespace fc {
 
+// A complex value.  Under clang (hipcc: device code and the host side of the library) it is a
+// 2-lane float vector, so that a value always lives in one aligned 64-bit register pair and sums
+// and products map to the packed-FP32 instructions of CDNA3/4 (v_pk_add_f32, v_pk_mul_f32,
+// v_pk_fma_f32: two lanes per issue slot -- the hot kernels are VALU-issue bound).  The swizzled
+// forms (multiplication by +-i, complex products) are single packed instructions with op_sel /
+// neg modifiers, which the compiler does not fold by itself: see the FC_PK_* helpers below.
+// Under g++ (tests/emu, test infrastructure) it is a plain struct with the same layout.
+#if defined(__clang__)
+typedef float c32 __attribute__((ext_vector_type(2)));
+#define FC_C32_VECTOR 1
+#else
 struct alignas(8) c32 {
     float x, y;
 };
+#define FC_C32_VECTOR 0
+#endif
 
 FC_HD c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+#if !FC_C32_VECTOR
 FC_HD c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
 FC_HD c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
-FC_HD c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FC_NO_PACKED)
+#define FC_PACKED 1
+#else
+#define FC_PACKED 0
+#endif
+
+#if FC_PACKED
+// One packed instruction with source modifiers.  op_sel picks the half of each source that feeds
+// the LOW lane, op_sel_hi the half that feeds the HIGH lane (0 = .x, 1 = .y); neg_lo / neg_hi
+// negate a source in the low / high lane.
+#define FC_PK2(op, dst, a, b, mods) asm(op " %0, %1, %2 " mods : "=v"(dst) : "v"(a), "v"(b))
+#define FC_PK3(op, dst, a, b, c, mods) asm(op " %0, %1, %2, %3 " mods : "=v"(dst) : "v"(a), "v"(b), "v"(c))
+#define FC_PK3S(op, dst, a, sb, c, mods) asm(op " %0, %1, %2, %3 " mods : "=v"(dst) : "v"(a), "s"(sb), "v"(c))   // src1 in SGPRs (constants)
+#endif
+
+// a + i*b and a - i*b
+FC_HD c32 add_jb(c32 a, c32 b) {
+#if FC_PACKED
+    c32 r;   // (a.x - b.y, a.y + b.x)
+    FC_PK2("v_pk_add_f32", r, a, b, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]");
+    return r;
+#else
+    return mk(a.x - b.y, a.y + b.x);
+#endif
+}
+FC_HD c32 sub_jb(c32 a, c32 b) {
+#if FC_PACKED
+    c32 r;   // (a.x + b.y, a.y - b.x)
+    FC_PK2("v_pk_add_f32", r, a, b, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]");
+    return r;
+#else
+    return mk(a.x + b.y, a.y - b.x);
+#endif
+}
+// a * b
+FC_HD c32 cmul(c32 a, c32 b) {
+#if FC_PACKED
+    c32 t, r;   // t = a.x * b;  r = a.y * (-b.y, b.x) + t
+    FC_PK2("v_pk_mul_f32", t, a, b, "op_sel:[0,0] op_sel_hi:[0,1]");
+    FC_PK3("v_pk_fma_f32", r, a, b, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");
+    return r;
+#else
+    return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+}
 // a * conj(b)
-FC_HD c32 cmulc(c32 a, c32 b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+FC_HD c32 cmulc(c32 a, c32 b) {
+#if FC_PACKED
+    c32 t, r;   // t = a.x * (b.x, -b.y);  r = a.y * (b.y, b.x) + t
+    FC_PK2("v_pk_mul_f32", t, a, b, "op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]");
+    FC_PK3("v_pk_fma_f32", r, a, b, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1]");
+    return r;
+#else
+    return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#endif
+}
 FC_HD c32 conj(c32 a) { return mk(a.x, -a.y); }
-FC_HD c32 scale(c32 a, float s) { return mk(a.x * s, a.y * s); }
+FC_HD c32 scale(c32 a, float s) {
+#if FC_C32_VECTOR
+    return a * s;
+#else
+    return mk(a.x * s, a.y * s);
+#endif
+}
+// t + c * a (c real)
+FC_HD c32 fma_real(float c, c32 a, c32 t) {
+#if FC_C32_VECTOR
+    c32 cc = {c, c};
+    return __builtin_elementwise_fma(cc, a, t);
+#else
+    return mk(t.x + c * a.x, t.y + c * a.y);
+#endif
+}
+// t + i*s*a and t - i*s*a (s real): (t.x -+ s*a.y, t.y +- s*a.x)
+FC_HD c32 fma_js(float s, c32 a, c32 t) {
+#if FC_PACKED
+    c32 ss = {s, s}, r;
+    FC_PK3S("v_pk_fma_f32", r, a, ss, t, "op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]");
+    return r;
+#else
+    return mk(t.x - s * a.y, t.y + s * a.x);
+#endif
+}
 
 // Compile-time loop: f(std::integral_constant<int, I>) for I in [0, N).
 template <int I>
@@ -136,5 +230,6 @@ struct alignas(16) PairEntry {
     int b;  // LDS position of bin M-k
     c32 w;  // exp(-2*pi*i*k/N), N = 2M
 };
+static_assert(sizeof(c32) == 8 && alignof(c32) == 8 && sizeof(PairEntry) == 16, "complex layout");
 
 }  // namespace fc
