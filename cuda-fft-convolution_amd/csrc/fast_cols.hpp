@@ -21,6 +21,10 @@
 #define FC_COLS_DBG 0   // timing experiments only (wrong results): 1 skip pair pass, 2 no barriers between stages, 4 no gather loads, 8 no stores, 16 contiguous gather addresses (tiled mode)
 #endif
 
+#ifndef FC_COLS_NO_PREWAIT
+#define FC_COLS_NO_PREWAIT 0   // 1: A/B, without the vmcnt(0) ahead of the store burst
+#endif
+
 namespace fc {
 
 template <int M_, int R1_, int R2_, int R3_, int T_, int NT_>
@@ -341,6 +345,11 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         float* out = g.out + (size_t)kernel * g.out_kernel_stride;
         const int nout = g.fft_h >> 1;   // complex pairs per output column
         ctx.phase([&](int t, State&) {
+#if !FC_COLS_NO_PREWAIT
+            // the next tile's gather (issued in C1) has had two stages to arrive: take it off the
+            // memory counter now, so that landing it does not wait for the stores below
+            FC_WAIT_VMEM();
+#endif
             FC_NOUNROLL
             for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the prefetched tile stays in registers
                 const int idx = t + NT * r;

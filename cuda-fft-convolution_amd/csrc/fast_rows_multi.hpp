@@ -17,10 +17,18 @@
 
 namespace fc {
 
+template <class C>
+struct RowMultiState {
+    c32 s[C::R3];        // image spectrum of this thread's stage-3 butterfly (whole walk)
+    c32 x[C::RND1];      // kernel row of the current / next map
+    c32 w1[C::RND1];     // stage-1 base twiddle w_L^j of this thread's butterflies (same for every map)
+    int yoff[C::RND1];   // tiled intermediate: element offset of this thread's rows (same for every map)
+};
+
 template <class C, int NZ2, class Ctx>
 FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, int kernel0, int nk, int rows) {
     constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
-    using State = RowState<C, false>;
+    using State = RowMultiState<C>;
     c32* tw2 = lds + RPW * L;
     const int kw = g.kw;
     const int row0 = group * RPW;
@@ -41,6 +49,17 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
     ctx.phase_nosync([&](int t, State& st) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
         load_x(t, st, kernel0);
+        // loaded once: inside the walk a global load in P5 would have to be waited for together
+        // with the stores issued just before it (one in-order memory counter)
+        static_for<0, C::RND1>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            const int u = t + NT * r;
+            const int rr = u / C::NB1, j = u - rr * C::NB1;
+            const int row = row0 + rr;
+            const bool live = rr < RPW && row < rows;
+            st.w1[r] = live ? g.tw1[j] : mk(1.f, 0.f);
+            st.yoff[r] = live ? (tiled ? (g.y_row_of[row] << g.y_tile_shift) : row * g.y_pitch) : 0;
+        });
         const int rr = t / C::NB3, q = t - rr * C::NB3;
         if (rr < RPW && row0 + rr < rows) {
             const c32* srow = g.S + (size_t)(row0 + rr) * g.s_pitch;
@@ -67,9 +86,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 if (rr < RPW && j < kw) {
                     c32* buf = lds + rr * L;
                     c32 p[R1];
-                    int jj = j;
-                    FC_OPAQUE(jj);   // the twiddle chain is recomputed per map, not kept across the loop
-                    power_chain<R1>(g.tw1[jj], p);
+                    power_chain<R1>(st.w1[r], p);
                     buf[j] = st.x[r];
                     static_for<1, R1>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;
@@ -162,7 +179,10 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         // P5: inverse stage 1 straight to global memory; the barrier protects the LDS row
         // against the next map's P1
         c32* ybase = g.Y + (size_t)kernel * g.y_kernel_stride;
-        ctx.phase([&](int t, State&) {
+        ctx.phase([&](int t, State& st) {
+            // the next kernel row (prefetched after P1) has had three phases to arrive: take it off
+            // the memory counter before the store burst, or the next P1 would wait for these stores
+            FC_WAIT_VMEM();
             static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 int u = t + NT * r;
@@ -172,7 +192,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 if (rr < RPW && row < rows) {
                     const c32* buf = lds + rr * L;
                     c32 p[R1];
-                    power_chain<R1>(g.tw1[j], p);
+                    power_chain<R1>(st.w1[r], p);
                     c32 v[R1];
                     v[0] = buf[j];
                     static_for<1, R1>([&](auto c_) {
@@ -180,7 +200,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         v[c] = cmulc(buf[c * m1 + j], p[c]);
                     });
                     Dft<R1, +1>::run(v);
-                    c32* yrow = ybase + (tiled ? ((size_t)g.y_row_of[row] << g.y_tile_shift) : (size_t)row * g.y_pitch);
+                    c32* yrow = ybase + st.yoff[r];
                     static_for<0, R1>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
                         int w = j + a * m1;

@@ -82,6 +82,17 @@
 #define FC_OPAQUE(x) ((void)0)
 #endif
 
+// Wait for every outstanding vector-memory operation of this wave (s_waitcnt vmcnt(0); gfx9
+// encoding, the other counters left alone).  vmcnt counts loads and stores together and in
+// order: a prefetch issued BEFORE a burst of stores can otherwise only be waited for together
+// with (most of) those stores.  Placing this right before the burst -- when the prefetch has had
+// several phases to arrive -- keeps the store latency off the critical path.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FC_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define FC_WAIT_VMEM() ((void)0)
+#endif
+
 namespace fc {
 
 // A complex value.  Under clang (hipcc: device code and the host side of the library) it is a

@@ -356,9 +356,10 @@ BatchSizes batch_sizes(const fftconv_plan* p, int n, int kw) {
     const size_t y_bytes = g.y_elems_per_kernel() * sizeof(c32);
     // maps per launch.  auto: enough to amortise the last partially filled wave of workgroups (the
     // two hot kernels run ~2 "rounds" of workgroups per map on 256 CUs; 32 maps make both round
-    // counts nearly integral at cfg3), capped at 2.5 GiB of intermediate
+    // counts nearly integral at cfg3, and 64 let the multi-map row kernel walk 16 maps per workgroup
+    // on a grid that still fills the chip), capped at 5 GiB of intermediate
     b.nbY = (int)p->opt_batch_maps;
-    if (b.nbY <= 0) b.nbY = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)2560 << 20) / y_bytes));
+    if (b.nbY <= 0) b.nbY = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)5120 << 20) / y_bytes));
     b.nbY = std::min(b.nbY, n);
     // kernels per column-spectrum chunk: a multiple of nbY within 512 MiB
     const size_t a_budget = (size_t)512 << 20;
@@ -519,9 +520,9 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
             if (g.y_pre()) {
                 FastRowsPairArgs fa = fast_rows_pair_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_fast_rows_pair(g.Lw, fast_rows_nz2(g, kw), fa, g.M / 2 + 1, ny, p->stream));
-            } else if (g.rows_multi()) {
+            } else if (g.rows_group_for(ny, p->num_cus) > 1) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
-                HIP_TRY(launch_fast_rows_multi(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_group, p->stream));
+                HIP_TRY(launch_fast_rows_multi(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_group_for(ny, p->num_cus), p->stream));
             } else if (g.fast_rows.ok) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_persistent ? 4 * p->num_cus : 0, g.rows_wg_order, p->stream));

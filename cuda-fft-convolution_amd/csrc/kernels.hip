@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_multi(FastRowsArgs a, 
     const int group = (int)blockIdx.x;
     const int kernel0 = (int)blockIdx.y * per_wg;
     const int nk = kernels - kernel0 < per_wg ? kernels - kernel0 : per_wg;
-    DevPhaseCtx<RowState<Cfg, false>> ctx;
+    DevPhaseCtx<RowMultiState<Cfg>> ctx;
     fast_rows_multi_body<Cfg, NZ2>(ctx, reinterpret_cast<c32*>(fc_smem), a, group, kernel0, nk, rows);
 }
 

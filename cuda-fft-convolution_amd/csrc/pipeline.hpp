@@ -54,8 +54,20 @@ struct Geometry {
     int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
     int y_row_order = 0;       // see make_fast_cols_tables
     int rows_wg_order = 0;     // workgroup order of the fast row kernel (kernels.hip: k_fast_rows); 1, 2 measured equal
-    int rows_group = 0;        // > 1: maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1)
-    bool rows_multi() const { return rows_group > 1 && F == 1 && fast_rows.ok && !y_pre() && !rows_persistent; }
+    // maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1): -1 = chosen per
+    // launch (rows_group_for), 0 / 1 = plain one-map kernel, > 1 = fixed (A/B runs)
+    int rows_group = -1;
+    bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && F == 1 && fast_rows.ok && !y_pre() && !rows_persistent; }
+    // As many maps per workgroup as leaves >= 4 workgroups per resident slot (4 per CU), at most 16:
+    // the walk amortises the image-spectrum row, the launch and the store drain, but a grid
+    // that no longer fills the chip loses more than that.
+    int rows_group_for(int nmaps, int num_cus) const {
+        if (!rows_multi_ok()) return 1;
+        if (rows_group > 1) return std::min(rows_group, nmaps);
+        const long groups = (rows + fast_rows.RPW - 1) / fast_rows.RPW;
+        const long g = groups * nmaps / ((long)num_cus * 16);
+        return (int)std::max<long>(1, std::min<long>(16, std::min<long>(g, nmaps)));
+    }
     bool rows_persistent = false; // persistent variant of the fast single-row kernel (measured slower: kept for A/B)
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {

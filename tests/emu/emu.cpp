@@ -62,7 +62,7 @@ struct EmuFastRows {
             b.y_kernel_stride = 0;
             for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
                 for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-                HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
+                HostPhaseCtx<RowMultiState<Cfg>> ctx(Cfg::NT);
                 fast_rows_multi_body<Cfg, NZ2>(ctx, lds, b, grp, 0, group, rows);
             }
             return;
@@ -262,7 +262,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fr_tw1 = t.fr.tw1.data();
             d.fr_tw2 = t.fr.tw2.data();
             FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
-            EmuFastRows run{fa, lds.data(), g.rows, g.rows_persistent, g.rows_multi() ? g.rows_group : 0};
+            EmuFastRows run{fa, lds.data(), g.rows, g.rows_persistent, (g.rows_multi_ok() && g.rows_group > 1) ? g.rows_group : 0};
             if (!fast_rows_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
         } else {
             SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());

@@ -76,6 +76,7 @@ def set_variant(monkeypatch, v):
     monkeypatch.setenv("FFTCONV_ROW_ORDER", str(ro))
     monkeypatch.setenv("FFTCONV_ROWS_PERSIST", str(pers))
     monkeypatch.setenv("FFTCONV_PATH_MODE", str(mode))
+    monkeypatch.setenv("FFTCONV_ROWS_GROUP", str(v[7] if len(v) > 7 else -1))   # -1: chosen per launch
 
 
 @pytest.mark.parametrize("shape", ROW_SHAPES + COL_SHAPES)
@@ -117,6 +118,20 @@ def test_emulated_fast_kernels_other_configs(emu, oracle, monkeypatch, shape, mo
     data, ks = make_inputs(shape, 29)
     rc, got = emu_conv(emu, data, kh, kw, ks)
     emu.emu_allow_fast(2)
+    assert rc == 0
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [ROW_SHAPES[0], (256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 1), (2048, 300, 1, 63, 20, 1)])
+def test_emulated_multi_map_row_kernel(emu, oracle, monkeypatch, shape):
+    """fast_rows_multi.hpp (several maps per workgroup): the walk, its prefetch slot and the LDS reuse
+    through the emulator (which repeats one kernel; distinct kernels per walk are a GPU test)"""
+    set_variant(monkeypatch, (2, 16, 0, 0, 1, 0, 1, 3))
+    emu.emu_allow_fast(2)
+    H, W, F, kh, kw, n = shape
+    data, ks = make_inputs(shape, 43)
+    rc, got = emu_conv(emu, data, kh, kw, ks)
     assert rc == 0
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < 1e-5
@@ -178,3 +193,40 @@ def test_gpu_fast_kernels_many_maps_multi_feature(fftconv, oracle):
             ref = oracle.conv_fft(data, kh, kw, ks)
             for g, r in zip(got, ref):
                 assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [2, 5, -1])
+@pytest.mark.parametrize("shape", [(40, 4096, 1, 7, 127, 7), (2048, 300, 1, 63, 20, 7), (1024, 1024, 1, 63, 63, 7),
+                                   (256, 256, 1, 31, 31, 7), (300, 4096, 1, 20, 63, 11)])
+def test_gpu_multi_map_row_kernel(fftconv, oracle, monkeypatch, shape, group):
+    """several maps per workgroup with DISTINCT kernels (walk indexing, prefetch of the next kernel
+    row, partial last walk: 7 = 2+2+2+1 = 5+2) on every fast row configuration"""
+    set_variant(monkeypatch, (2, 16, 0, 0, 1, 0, 1, group))
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(1000 + group)
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(n)]
+    with fftconv.Plan(H, W, F, kh, kw) as p:
+        p.set_image(data)
+        got = p.convolve(ks)
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle, monkeypatch):
+    """enough maps that the per-launch choice walks several maps per workgroup (cfg1-sized maps)"""
+    set_variant(monkeypatch, (2, 16, 0, 0, 1, 0, 1, -1))
+    H, W, kh, kw, n = 256, 256, 31, 31, 1500
+    rng = np.random.default_rng(99)
+    data = rng.random((H, W, 1), dtype=np.float32)
+    ks = [rng.random((kh, kw, 1), dtype=np.float32) for _ in range(n)]
+    with fftconv.Plan(H, W, 1, kh, kw) as p:
+        p.set_option("batch_maps", 1500)
+        p.set_image(data)
+        got = p.convolve(ks)
+    idx = [0, 1, 15, 16, 17, 700, 1498, 1499]
+    ref = oracle.conv_fft(data, kh, kw, [ks[i] for i in idx])
+    for i, r in zip(idx, ref):
+        assert util.rel_err(got[i], r) < 1e-5
