@@ -243,6 +243,8 @@ struct fftconv_plan {
     DevBuf<c32> A;     // kernel column spectra of the current chunk
     DevBuf<c32> Y;     // intermediate of the current map batch
     DevBuf<float> K;   // packed kernels staged on the device
+    DevBuf<float> KF;  // flipped copy of the current chunk of kernels ("flip_kernels")
+    long opt_flip_kernels = 0;
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
     DevBuf<c32> fr_tw1, fr_tw2;
@@ -321,7 +323,7 @@ struct fftconv_plan {
         pending.clear();
         pool.clear();
         tw_m.release(); tw_w.release(); pairs.release();
-        S.release(); A.release(); Y.release(); K.release(); O.release(); I.release();
+        S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); I.release();
         fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release(); fc_pair_row_of.release(); fc_pair_row_seq.release();
         cw_tw3.release(); cw_twA.release(); cw_twF.release(); cw_wh.release(); cw_wl.release();
@@ -473,6 +475,13 @@ int ring_drain(fftconv_plan* p, const Sink& sink, int first, int count, int buf,
 // h-transform of the kernels [a0, a0 + na) of a packed group into the column-spectrum buffer A
 int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh, int kw) {
     const Geometry& g = p->g;
+    if (p->opt_flip_kernels) {   // template matching: correlate instead of convolve (demoCudaConvolutionFFT.m:63-69)
+        const size_t chunk = (size_t)na * g.F * kh * kw;
+        if (int rc = p->KF.ensure(chunk)) return rc;
+        HIP_TRY(launch_flip_planes(dk + (size_t)a0 * g.F * kh * kw, p->KF.p, kh * kw, (long)na * g.F, p->stream));
+        dk = p->KF.p;
+        a0 = 0;
+    }
     if (int rc = p->prof_begin(PK_KERNEL_COLS, na)) return rc;
     if (g.fast_fwd) {
         FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dk + (size_t)a0 * g.F * kh * kw, (size_t)kh * kw, kh, kh, kw, na * g.F,
@@ -897,6 +906,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "flip_kernels")) { plan->opt_flip_kernels = value != 0; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "host_stream") || !strcmp(name, "host_threads") || !strcmp(name, "host_chunk_kb") || !strcmp(name, "host_slots")) {
         if (value < 0 || value > (1 << 20)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);
         if (int rc = use_device(plan)) return rc;

@@ -39,6 +39,16 @@ __global__ void __launch_bounds__(512) k_cols_c2r(ColsC2RArgs a) {
     cols_c2r_body(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// Reverses every plane of `pe` floats: for a column-major kh x kw plane that is the flip along both
+// axes, kernel(end:-1:1, end:-1:1, f) of demoCudaConvolutionFFT.m:67-69.
+__global__ void __launch_bounds__(256) k_flip_planes(const float* __restrict__ src, float* __restrict__ dst, int pe, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long plane = i / pe;
+        const int e = (int)(i - plane * pe);
+        dst[i] = src[plane * pe + (pe - 1 - e)];
+    }
+}
+
 // Raises the dynamic-LDS limit of a kernel once per device (the attribute is per device; a
 // process may drive several GPUs through different plans).
 template <class K>
@@ -372,6 +382,14 @@ hipError_t launch_fast_cols_wide(int M, const FastColsWideArgs& a, int num_cus, 
     FastColsWideLauncher l{a, num_cus, s};
     if (!fast_cols_wide_dispatch(M, l)) return hipErrorInvalidValue;
     return l.err;
+}
+
+hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, long nplanes, hipStream_t s) {
+    const long total = (long)plane_elems * nplanes;
+    if (total <= 0) return hipSuccess;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_flip_planes, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, src, dst, plane_elems, total);
+    return hipGetLastError();
 }
 
 hipError_t kernels_init() {

@@ -10,6 +10,8 @@ namespace fc {
 // Raises the dynamic-LDS limit of every kernel to the full 160 KiB of a gfx950 CU.
 hipError_t kernels_init();
 
+// dst plane = src plane reversed (flip of a column-major kh x kw plane along both axes)
+hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, long nplanes, hipStream_t s);
 hipError_t launch_cols_r2c(const ColsR2CArgs& a, int tiles, int planes, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);

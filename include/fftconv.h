@@ -171,7 +171,11 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             cudaMemcpy per map, src/cudaConvolutionFFT.cu:284-286: 0 = blocking copies after each
  *             batch; 1 (default) = host threads of the plan copy batch b straight into the caller's
  *             buffers while batch b+1 is computed; 2 = through a ring of pinned chunks),
- *          "host_threads", "host_chunk_kb", "host_slots" (shape of that machinery, 0 = auto). */
+ *          "host_threads", "host_chunk_kb", "host_slots" (shape of that machinery, 0 = auto),
+ *          "flip_kernels" (1: every kernel is flipped along h and w on the device before it is
+ *             transformed, i.e. the plan correlates -- the "Flip Kernel (Required)" step of
+ *             demoCudaConvolutionFFT.m:63-69 done here instead of in MATLAB; the reference keeps a
+ *             conjugate-product variant commented out, src/cudaConvFFTData.cuh:42-45,63). */
 int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
 
 typedef struct fftconv_profile {

@@ -352,3 +352,36 @@ def test_host_output_streaming_large_maps(fc, oracle):
     ref = oracle.conv_fft(img, 63, 63, ks)
     for g, r in zip(got, ref):
         assert util.rel_err(g, r) < TOL
+
+
+# ---- flip_kernels: the demo's "Flip Kernel (Required)" step done on the device ---------------------
+
+def test_flip_kernels_option_equals_flipping_by_hand(fc, oracle):
+    """demoCudaConvolutionFFT.m:63-69 flips every kernel (end:-1:1, end:-1:1, :) before the call so
+    that the convolution acts as template matching; with flip_kernels = 1 the plan does it."""
+    rng = np.random.default_rng(5)
+    H, W, F, kh, kw = 90, 75, 3, 8, 5
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(4)]
+    ks.append(rng.random((kh - 1, kw - 2, F), dtype=np.float32))
+    flipped = [np.ascontiguousarray(k[::-1, ::-1, :]) for k in ks]
+    with fc.Plan(H, W, F, kh, kw) as plan:
+        plan.set_image(data)
+        by_hand = plan.convolve(flipped)
+        plan.set_option("flip_kernels", 1)
+        on_device = plan.convolve(ks)
+        plan.set_option("flip_kernels", 0)
+        plain = plan.convolve(ks)
+    ref = oracle.conv_fft(data, kh, kw, flipped)
+    for a, b, c, r in zip(on_device, by_hand, plain, ref):
+        assert np.array_equal(a, b)
+        assert not np.array_equal(a, c)
+        assert util.rel_err(a, r) < TIGHT
+    # template matching: planting kernel 0 in the data makes its correlation peak there
+    data2 = data.copy()
+    data2[20:20 + kh, 30:30 + kw, :] = 3.0 * ks[0]
+    with fc.Plan(H, W, F, kh, kw) as plan:
+        plan.set_option("flip_kernels", 1)
+        plan.set_image(data2)
+        m = plan.convolve([ks[0]])[0]
+    assert np.unravel_index(np.argmax(m), m.shape) == (20 + kh - 1, 30 + kw - 1)

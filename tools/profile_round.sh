@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profiles of the default bench (cfg3): kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in
+# separate counter passes.  Usage (on the GPU box): bash tools/profile_round.sh r01f
+set -e
+TAG=${1:-r01x}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
+find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+( echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 (cfg3 defaults)";
+  echo "# units: KB per dispatch (mean over dispatches of that grid size); gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)";
+  python3 tools/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") ) > $OUT/pmc_fetch_write.txt
+find $OUT -name "*.csv" -size +2M -delete
+find $OUT -name "*.db" -delete
+ls -la $OUT
