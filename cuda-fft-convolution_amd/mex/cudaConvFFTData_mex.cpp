@@ -1,0 +1,51 @@
+// cudaConvFFTData_mex.cpp -- MATLAB MEX gateway, step 2 of the reference's two-step API
+// (src/cudaConvFFTData.cu:24-306):
+//
+//   cvcell = cudaConvFFTData(fftData, kernelCell[, threadSize])
+//
+// fftData is the handle returned by cudaFFTData (the reference takes the complex gpuArray,
+// src/cudaConvFFTData.cu:68-69,90-91); the image spectrum it stands for is reused for every call.
+#include <cstdint>
+#include <vector>
+
+#include "fftconv.h"
+#include "mex.h"
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    const char* errId = FFTCONV_MEX_ERROR_ID;   // "cudaConvFFTData:InvalidInput" (src/cudaConvFFTData.cu:47)
+    (void)nlhs;
+    if (nrhs < 2 || nrhs > 3 || mxGetClassID(prhs[0]) != mxUINT64_CLASS || mxGetNumberOfElements(prhs[0]) != 1)
+        mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");               // :68-69
+    const double* threads = nullptr;
+    int nthreads = 0;
+    if (nrhs > 2) {                                                                          // :71-72: checked by the library
+        threads = static_cast<const double*>(mxGetData(prhs[2]));
+        nthreads = (int)mxGetNumberOfElements(prhs[2]);
+    }
+    if (mxGetClassID(prhs[1]) != mxCELL_CLASS) mexErrMsgIdAndTxt(errId, "Kernel must be a cell array");   // :108-109
+    fftconv_plan* plan = reinterpret_cast<fftconv_plan*>((uintptr_t) * static_cast<const uint64_t*>(mxGetData(prhs[0])));
+    fftconv_plan_info info;
+    if (fftconv_plan_get_info(plan, &info) != FFTCONV_OK) mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
+    const int n = (int)mxGetNumberOfElements(prhs[1]);
+    std::vector<const float*> kp(n);
+    std::vector<int> kh(n), kw(n), kf(n);
+    for (int k = 0; k < n; k++) {
+        const mxArray* c = mxGetCell(prhs[1], k);
+        const mwSize knd = c ? mxGetNumberOfDimensions(c) : 0;
+        if (!c || mxGetClassID(c) != mxSINGLE_CLASS || knd < 2 || knd > 3)
+            mexErrMsgIdAndTxt(errId, "Kernels must be of type float and have features larger than 1");   // :150-151
+        const mwSize* kd = mxGetDimensions(c);
+        kp[k] = static_cast<const float*>(mxGetData(c));
+        kh[k] = (int)kd[0]; kw[k] = (int)kd[1]; kf[k] = knd == 3 ? (int)kd[2] : 1;
+    }
+    plhs[0] = mxCreateCellMatrix(1, n);                                                      // :112
+    std::vector<float*> out(n);
+    const mwSize cdims[2] = {(mwSize)info.fft_h, (mwSize)info.fft_w};
+    for (int k = 0; k < n; k++) {
+        mxArray* m = mxCreateNumericArray(2, cdims, mxSINGLE_CLASS, mxREAL);                 // :277-281
+        out[k] = static_cast<float*>(mxGetData(m));
+        mxSetCell(plhs[0], k, m);
+    }
+    if (fftconv_conv_fft_data(plan, n, kp.data(), kh.data(), kw.data(), kf.data(), threads, nthreads, out.data()) != FFTCONV_OK)
+        mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
+}

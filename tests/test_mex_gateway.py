@@ -1,0 +1,187 @@
+"""The three MATLAB MEX gateways (cuda-fft-convolution_amd/mex/*.cpp), compiled against a TEST-ONLY
+miniature of mex.h (tests/mexmock) because MATLAB is not in the image, and driven through their real
+`mexFunction` entry points with the reference's positional signatures
+(src/cudaConvolutionFFT.cu:15-22, src/cudaFFTData.cu:10-14, src/cudaConvFFTData.cu:15-22).
+CPU tier: they build, export mexFunction and raise the reference's error id / messages for bad
+arguments before anything touches a device.  GPU tier: results equal the oracle's."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+MOCK_DIR = os.path.join(util.ROOT, "tests", "mexmock")
+SINGLE, DOUBLE, UINT64, CELL = 7, 6, 13, 1
+ERR_ID = "cudaConvFFTData:InvalidInput"      # src/cudaConvolutionFFT.cu:30
+
+
+class Mex:
+    def __init__(self):
+        util.load_package().load_library()   # libfftconv.so (and one HIP runtime) first
+        subprocess.run(["make", "-C", MOCK_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        self.rt = ctypes.CDLL(os.path.join(MOCK_DIR, "libmexmock.so"), mode=ctypes.RTLD_GLOBAL)
+        vp = ctypes.c_void_p
+        self.rt.mock_new_numeric.restype = vp
+        self.rt.mock_new_numeric.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
+        self.rt.mock_new_cell.restype = vp
+        self.rt.mock_set_cell.argtypes = [vp, ctypes.c_int, vp]
+        self.rt.mock_get_cell.restype = vp
+        self.rt.mock_get_cell.argtypes = [vp, ctypes.c_int]
+        self.rt.mock_class.argtypes = [vp]
+        self.rt.mock_ndim.argtypes = [vp]
+        self.rt.mock_dim.restype = ctypes.c_uint64
+        self.rt.mock_dim.argtypes = [vp, ctypes.c_int]
+        self.rt.mock_data.restype = vp
+        self.rt.mock_data.argtypes = [vp]
+        self.rt.mock_free.argtypes = [vp]
+        self.rt.mock_error_id.restype = ctypes.c_char_p
+        self.rt.mock_error_msg.restype = ctypes.c_char_p
+        self.rt.mock_call.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
+        self.gw = {n: ctypes.CDLL(os.path.join(MOCK_DIR, n + ".mexmock.so"))
+                   for n in ("cudaConvolutionFFT", "cudaFFTData", "cudaConvFFTData")}
+
+    # -- MATLAB values
+    def numeric(self, a):
+        a = np.asfortranarray(a)
+        cls = {np.dtype(np.float32): SINGLE, np.dtype(np.float64): DOUBLE, np.dtype(np.uint64): UINT64}[a.dtype]
+        shape = a.shape if a.ndim >= 2 else (a.shape + (1, 1))[:2]
+        dims = (ctypes.c_uint64 * len(shape))(*shape)
+        return self.rt.mock_new_numeric(cls, len(shape), dims, a.ctypes.data_as(ctypes.c_void_p))
+
+    def scalar(self, v):
+        return self.numeric(np.array([[float(v)]], dtype=np.float64))
+
+    def cell(self, items):
+        c = self.rt.mock_new_cell(len(items))
+        for i, it in enumerate(items):
+            self.rt.mock_set_cell(c, i, it)
+        return c
+
+    def to_numpy(self, m):
+        shape = tuple(self.rt.mock_dim(m, i) for i in range(self.rt.mock_ndim(m)))
+        cls = self.rt.mock_class(m)
+        dt = {SINGLE: np.float32, DOUBLE: np.float64, UINT64: np.uint64}[cls]
+        n = int(np.prod(shape))
+        buf = (ctypes.c_char * (n * np.dtype(dt).itemsize)).from_address(self.rt.mock_data(m))
+        return np.frombuffer(buf, dtype=dt).reshape(shape, order="F").copy()
+
+    def call(self, name, args, nlhs=1):
+        """-> (raised, outputs or (id, message))"""
+        fn = ctypes.cast(self.gw[name].mexFunction, ctypes.c_void_p)
+        prhs = (ctypes.c_void_p * max(1, len(args)))(*args)
+        plhs = (ctypes.c_void_p * max(1, nlhs))()
+        rc = self.rt.mock_call(fn, nlhs, plhs, len(args), prhs)
+        if rc:
+            return True, (self.rt.mock_error_id().decode(), self.rt.mock_error_msg().decode())
+        return False, [plhs[i] for i in range(nlhs)]
+
+    def cell_to_list(self, c, n):
+        return [self.to_numpy(self.rt.mock_get_cell(c, i)) for i in range(n)]
+
+
+@pytest.fixture(scope="module")
+def mex():
+    return Mex()
+
+
+def demo_inputs(seed=3):
+    rng = np.random.default_rng(seed)
+    data = rng.random((64, 8, 5), dtype=np.float32)                 # demoCudaConvolutionFFT.m:37-42
+    ks = [rng.random((10, 4, 5), dtype=np.float32) for _ in range(3)]
+    return data, ks
+
+
+def test_gateways_build_and_export_mexfunction(mex):
+    for name, lib in mex.gw.items():
+        assert hasattr(lib, "mexFunction"), name
+
+
+def test_argument_errors_match_the_reference(mex):
+    data, ks = demo_inputs()
+    d, kc = mex.numeric(data), mex.cell([mex.numeric(k) for k in ks])
+    # src/cudaConvolutionFFT.cu:45-46
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [d, mex.scalar(10), mex.scalar(4)])
+    assert raised and eid == ERR_ID and msg == "Wrong number of inputs"
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [d] * 7)
+    assert raised and msg == "Wrong number of inputs"
+    # :51-54 data must be single
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [mex.numeric(data.astype(np.float64)), mex.scalar(10), mex.scalar(4), kc])
+    assert raised and msg == "Invalid data input"
+    # :64-65
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [d, mex.scalar(10), mex.scalar(4), mex.numeric(ks[0])])
+    assert raised and eid == ERR_ID and msg == "Kernel must be a cell array"
+    # :72-73 thread size must have 4 elements
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [d, mex.scalar(10), mex.scalar(4), kc, mex.numeric(np.array([[8.0, 8.0, 8.0]]))])
+    assert raised and eid == ERR_ID and msg.startswith("CUDA Thread Size must be 4 integers")
+    # :210-211 kernels must be single
+    bad = mex.cell([mex.numeric(ks[0].astype(np.float64))])
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [d, mex.scalar(10), mex.scalar(4), bad])
+    assert raised and eid == ERR_ID and msg.startswith("Kernels must be of type float")
+    # :242-243 feature mismatch
+    bad = mex.cell([mex.numeric(ks[0][:, :, :3].copy())])
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [d, mex.scalar(10), mex.scalar(4), bad])
+    assert raised and eid == ERR_ID and msg.startswith("Kernel and Data must have the same number of features")
+    # two-step gateways: src/cudaFFTData.cu:49-54, src/cudaConvFFTData.cu:68-69,108-109
+    raised, (eid, msg) = mex.call("cudaFFTData", [d, mex.scalar(10)])
+    assert raised and eid == "parallel:gpu:mexGPUExample:InvalidInput" and msg == "Invalid input to MEX file."
+    raised, (eid, msg) = mex.call("cudaFFTData", [mex.numeric(data.astype(np.float64)), mex.scalar(10), mex.scalar(4)])
+    assert raised and msg == "Invalid input to MEX file."
+    raised, (eid, msg) = mex.call("cudaConvFFTData", [d, kc])
+    assert raised and eid == ERR_ID and msg == "The data must be FFT-ed real array in GPU"
+
+
+def test_without_a_gpu_a_valid_call_raises_a_mex_error_instead_of_exiting(mex, fftconv):
+    if fftconv.device_count() > 0:
+        pytest.skip("a GPU is present")
+    data, ks = demo_inputs()
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [mex.numeric(data), mex.scalar(10), mex.scalar(4),
+                                                         mex.cell([mex.numeric(k) for k in ks])])
+    assert raised and eid == ERR_ID and "HIP device" in msg      # the reference would exit(): src/cudaConvFFTData.h:6-29
+
+
+@pytest.mark.gpu
+def test_one_shot_gateway_matches_oracle(mex, oracle):
+    data, ks = demo_inputs()
+    args = [mex.numeric(data), mex.scalar(10), mex.scalar(4), mex.cell([mex.numeric(k) for k in ks]),
+            mex.numeric(np.array([[8.0, 8.0, 8.0, 16.0]])), mex.scalar(0)]       # demoCudaConvolutionFFT.m:124-129
+    raised, out = mex.call("cudaConvolutionFFT", args)
+    assert not raised, out
+    got = mex.cell_to_list(out[0], len(ks))
+    for g, r in zip(got, oracle.conv_fft(data, 10, 4, ks)):
+        assert g.shape == (80, 16) and g.dtype == np.float32       # full ceil16 window (:198-200)
+        assert util.rel_err(g, r) < 1e-5
+    # 4 arguments (no thread size, no gpu id) and a 2-D image with 2-D kernels (F = 1)
+    img = np.random.default_rng(1).random((50, 40), dtype=np.float32)
+    k2 = [np.random.default_rng(2).random((7, 5), dtype=np.float32)]
+    raised, out = mex.call("cudaConvolutionFFT", [mex.numeric(img), mex.scalar(7), mex.scalar(5), mex.cell([mex.numeric(k) for k in k2])])
+    assert not raised, out
+    assert util.rel_err(mex.cell_to_list(out[0], 1)[0], oracle.conv_fft(img, 7, 5, k2)[0]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_two_step_gateways_match_one_shot(mex, oracle):
+    data, ks = demo_inputs(9)
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
+    assert not raised, out
+    handle = out[0]
+    assert mex.to_numpy(handle).dtype == np.uint64
+    ref = oracle.conv_fft(data, 10, 4, ks)
+    for rep in range(2):       # the spectrum is reused across calls
+        raised, out = mex.call("cudaConvFFTData", [handle, mex.cell([mex.numeric(k) for k in ks]),
+                                                   mex.numeric(np.array([[8.0, 8.0, 8.0, 16.0]]))])
+        assert not raised, out
+        for g, r in zip(mex.cell_to_list(out[0], len(ks)), ref):
+            assert util.rel_err(g, r) < 1e-5
+    raised, (eid, msg) = mex.call("cudaConvFFTData", [handle, mex.cell([mex.numeric(k) for k in ks]), mex.numeric(np.array([[8.0, 8.0]]))])
+    assert raised and msg.startswith("CUDA Thread Size must be 4 integers")
+    # release: explicit, then twice = error; whatever is left goes at `clear mex`
+    raised, _ = mex.call("cudaFFTData", [handle], nlhs=0)
+    assert not raised
+    raised, _ = mex.call("cudaFFTData", [handle], nlhs=0)
+    assert raised
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
+    assert not raised
+    mex.rt.mock_run_at_exit()
