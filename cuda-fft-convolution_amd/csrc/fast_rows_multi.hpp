@@ -25,7 +25,13 @@ struct RowMultiState {
     int yoff[C::RND1];   // tiled intermediate: element offset of this thread's rows (same for every map)
 };
 
-template <class C, int NZ2, class Ctx>
+// LINEAR (chosen by the launcher with fast_rows_multi_linear): see P5.
+inline bool fast_rows_multi_linear(const FastRowsArgs& g, int L, int m1) {
+    const bool tiled = g.y_row_of != nullptr;
+    return g.wout >= L && (!tiled || (m1 & ((1 << g.y_tile_shift) - 1)) == 0);
+}
+
+template <class C, int NZ2, bool LINEAR, class Ctx>
 FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, int kernel0, int nk, int rows) {
     constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
     using State = RowMultiState<C>;
@@ -183,6 +189,39 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             // the next kernel row (prefetched after P1) has had three phases to arrive: take it off
             // the memory counter before the store burst, or the next P1 would wait for these stores
             FC_WAIT_VMEM();
+            // LINEAR: the R1 outputs of a butterfly are m1 columns apart; when that is a whole number
+            // of layout tiles (or the intermediate is row-major) and nothing is cropped, output a
+            // sits at base + a * stride: a scalar base, one 32-bit add per store, no 64-bit tile
+            // arithmetic and no bounds compare (a fifth of this kernel's VALU instructions)
+            if constexpr (LINEAR) {
+                char* yb = reinterpret_cast<char*>(ybase);
+                const unsigned stride_b = (unsigned)((tiled ? (m1 >> g.y_tile_shift) * g.y_tile_elems : m1) * (int)sizeof(c32));
+                static_for<0, C::RND1>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    int u = t + NT * r;
+                    FC_OPAQUE(u);
+                    const int rr = u / C::NB1, j = u - rr * C::NB1;
+                    if (rr < RPW && row0 + rr < rows) {
+                        const c32* buf = lds + rr * L;
+                        c32 p[R1];
+                        power_chain<R1>(st.w1[r], p);
+                        c32 v[R1];
+                        v[0] = buf[j];
+                        static_for<1, R1>([&](auto c_) {
+                            constexpr int c = decltype(c_)::value;
+                            v[c] = cmulc(buf[c * m1 + j], p[c]);
+                        });
+                        Dft<R1, +1>::run(v);
+                        const int jo = tiled ? (j >> g.y_tile_shift) * g.y_tile_elems + (j & ((1 << g.y_tile_shift) - 1)) : j;
+                        const unsigned off0 = (unsigned)(st.yoff[r] + jo) * (unsigned)sizeof(c32);
+                        static_for<0, R1>([&](auto a_) {
+                            constexpr int a = decltype(a_)::value;
+                            FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                        });
+                    }
+                    FC_SCHED_FENCE();
+                });
+            } else
             static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 int u = t + NT * r;

@@ -63,7 +63,8 @@ struct EmuFastRows {
             for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
                 for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
                 HostPhaseCtx<RowMultiState<Cfg>> ctx(Cfg::NT);
-                fast_rows_multi_body<Cfg, NZ2>(ctx, lds, b, grp, 0, group, rows);
+                if (fast_rows_multi_linear(b, Cfg::L, Cfg::m1)) fast_rows_multi_body<Cfg, NZ2, true>(ctx, lds, b, grp, 0, group, rows);
+                else fast_rows_multi_body<Cfg, NZ2, false>(ctx, lds, b, grp, 0, group, rows);
             }
             return;
         }
