@@ -145,8 +145,10 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 const int e = t + NT * r;
                 if (e < State::NPU) {
                     const c32* pr = Yt + ((size_t)(2 * (e / T2)) << g.y_tile_shift) + 2 * (e % T2);
-                    FC_STREAM_LOAD16(st.pa[r], pr);
-                    FC_STREAM_LOAD16(st.pb[r], pr + tw);
+                    if constexpr (!(FC_COLS_DBG & 4)) {
+                        FC_STREAM_LOAD16(st.pa[r], pr);
+                        FC_STREAM_LOAD16(st.pb[r], pr + tw);
+                    }
                 }
             });
         } else if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
