@@ -85,6 +85,10 @@ def main():
                     help="streamed mode (BASELINE configs[4]): each rank convolves this many images per step, every "
                          "image with its own kernels' maps, the next image's H2D copy (pinned host memory, side "
                          "stream) overlapped with the current image's compute; no collective")
+    ap.add_argument("--graph", action="store_true",
+                    help="record one step into a HIP graph (plan bound to the capturing stream) and time graph "
+                         "replays: removes the per-launch host cost that bounds the small configurations; "
+                         "single-GPU, non-streamed steps only")
     ap.add_argument("--no-overlap", action="store_true", help="blocking broadcast, no kernel-column overlap (A/B)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
@@ -192,9 +196,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    run_step = step
+    graph = None
+    if args.graph:
+        if use_dist or streamed:
+            raise SystemExit("--graph: single-GPU, non-streamed steps only")
+        step()                                   # scratch buffers are sized: nothing allocates from here on
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        cap_stream = torch.cuda.Stream(dev)
+        with torch.cuda.graph(graph, stream=cap_stream):
+            plan.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            step()
+        plan.set_stream(stream.cuda_stream)
+        run_step = graph.replay
+        for _ in range(max(1, args.warmup)):
+            run_step()
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run_step()
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -253,6 +274,7 @@ def main():
                                       "image-sharded" if streamed else "filter-sharded"),
                        "transform": [info.transform_h, info.transform_w],
                        "filters_per_gpu": nf,
+                       "hip_graph_replay": bool(args.graph),
                        "images_per_gpu_per_step": args.images if streamed else 1,
                        "parallelism": ("images x%d, streamed H2D" % world) if streamed else
                                       ("filters x%d + 1 bcast" % world if world > 1 else "single GPU")},

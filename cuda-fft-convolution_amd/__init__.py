@@ -65,7 +65,7 @@ EXPORTED_SYMBOLS = (
     "fftconv_plan_set_image", "fftconv_plan_spectrum", "fftconv_plan_mark_spectrum_valid",
     "fftconv_plan_use_spectrum_buffer",
     "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_prepare_kernels_packed",
-    "fftconv_plan_synchronize",
+    "fftconv_plan_synchronize", "fftconv_plan_set_stream",
     "fftconv_plan_set_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
 )
 
@@ -121,6 +121,7 @@ def load_library():
     lib.fftconv_plan_convolve_packed.argtypes = [vp, ci, vp, ci, ci, vp]
     lib.fftconv_plan_prepare_kernels_packed.argtypes = [vp, ci, vp, ci, ci]
     lib.fftconv_plan_synchronize.argtypes = [vp]
+    lib.fftconv_plan_set_stream.argtypes = [vp, vp]
     lib.fftconv_plan_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
     lib.fftconv_plan_get_profile.argtypes = [vp, ctypes.POINTER(Profile), ci]
     lib.fftconv_fft_data.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
@@ -290,6 +291,10 @@ class Plan:
 
     def synchronize(self):
         _check(self._lib.fftconv_plan_synchronize(self._h))
+
+    def set_stream(self, stream):
+        """re-bind the plan to another HIP stream (integer handle, 0 = default stream)"""
+        _check(self._lib.fftconv_plan_set_stream(self._h, ctypes.c_void_p(int(stream) or None)))
 
     def set_option(self, name, value):
         _check(self._lib.fftconv_plan_set_option(self._h, name.encode(), int(value)))

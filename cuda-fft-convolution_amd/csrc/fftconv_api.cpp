@@ -895,6 +895,17 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
     return 0;
 }
 
+int fftconv_plan_set_stream(fftconv_plan* plan, void* hip_stream) {
+    if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (plan->profile && !plan->pending.empty()) {
+        if (int rc = use_device(plan)) return rc;
+        if (int rc = plan->prof_collect()) return rc;   // events recorded on the old stream
+    }
+    plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    plan->prepared.dk = nullptr;
+    return 0;
+}
+
 int fftconv_plan_synchronize(fftconv_plan* plan) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     if (int rc = use_device(plan)) return rc;

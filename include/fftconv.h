@@ -162,6 +162,14 @@ int fftconv_plan_convolve_packed(fftconv_plan *plan, int n_kernel, const float *
 int fftconv_plan_prepare_kernels_packed(fftconv_plan *plan, int n_kernel, const float *kernels_device,
                                         int kernel_h, int kernel_w);
 
+/* Re-bind the plan to another stream (NULL = the default stream).  Everything queued so far stays
+ * on the old stream; the caller orders the two.  After one warm-up call with the same arguments
+ * (which sizes the scratch buffers) fftconv_plan_set_image(DEVICE) and
+ * fftconv_plan_convolve_packed allocate nothing and never synchronise, so they can be recorded
+ * into a HIP graph: bind the plan to the capturing stream, capture, replay the graph
+ * (bench.py --graph; the launch-bound small configurations gain most). */
+int fftconv_plan_set_stream(fftconv_plan *plan, void *hip_stream);
+
 /* Block until everything queued on the plan's stream has finished. */
 int fftconv_plan_synchronize(fftconv_plan *plan);
 
