@@ -606,6 +606,83 @@ int check_thread_size(const double* thread_size, int n_thread_size) {
     return 0;
 }
 
+
+// One-shot entry for images whose padded size does not fit a single-pass plan: overlap-add.  The
+// image is cut into blocks of Bh x Bw samples, every block is convolved by an ordinary plan
+// (block + MAX_KERNEL - 1 <= 4224, the fastest specialised length), and the block results are
+// summed on the device into the full FFT_H x FFT_W maps at their offsets (convolution is linear
+// and the blocks partition the image).  The block spectra are computed once and kept; kernels are
+// processed in chunks that fit a few GiB of device maps.
+int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int mkw, int n, const float* const* kernels, const int* kh,
+                          const int* kw, int gpu_id, float* const* out) {
+    int limit = 4224;
+    if (const char* e = getenv("FFTCONV_MAX_TRANSFORM")) { const int v = atoi(e); if (v > 0) limit = std::min(limit, v); }
+    for (int k = 0; k < n; k++)
+        if (kh[k] > mkh || kw[k] > mkw)
+            return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel %dx%d exceeds MAX_KERNEL %dx%d (block-wise path)", kh[k], kw[k], mkh, mkw);
+    const int full_h = limit - mkh + 1, full_w = limit - mkw + 1;
+    if (full_h < 1 || full_w < 1)
+        return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "kernels up to %dx%d are too large for the block-wise path", mkh, mkw);
+    // fewest blocks first: tile only the dimension(s) that need it
+    const int cand[3][2] = {{H, std::min(W, full_w)}, {std::min(H, full_h), W}, {std::min(H, full_h), std::min(W, full_w)}};
+    fftconv_plan* sub = nullptr;
+    int Bh = 0, Bw = 0, rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
+    for (int c = 0; c < 3 && !sub; c++) {
+        Bh = cand[c][0]; Bw = cand[c][1];
+        rc = fftconv_plan_create(&sub, Bh, Bw, F, mkh, mkw, gpu_id, nullptr);
+        if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) return rc;
+    }
+    if (!sub) return rc;
+    const int nbh = (H + Bh - 1) / Bh, nbw = (W + Bw - 1) / Bw, nblk = nbh * nbw;
+    const int FH = fft_size16(H + mkh - 1), FW = fft_size16(W + mkw - 1);
+    const Geometry& g = sub->g;
+    const size_t big_map = (size_t)FH * FW, blk_map = g.map_elems(), spec_elems = g.spectrum_elems();
+    const size_t budget = (size_t)6 << 30;
+    const int nc = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / ((big_map + blk_map) * sizeof(float))));
+    DevBuf<c32> specs;
+    DevBuf<float> big, tmp;
+    std::vector<float> blk((size_t)Bh * Bw * F);
+    std::vector<float*> tptr(nc);
+    auto finish = [&](int code) {
+        const std::string keep = g_last_error;
+        (void)hipStreamSynchronize(sub->stream);
+        fftconv_plan_destroy(sub);
+        specs.release(); big.release(); tmp.release();
+        g_last_error = keep;
+        return code;
+    };
+    if ((rc = specs.ensure(spec_elems * nblk)) || (rc = big.ensure(big_map * nc)) || (rc = tmp.ensure(blk_map * nc))) return finish(rc);
+    for (int j = 0; j < nc; j++) tptr[j] = tmp.p + (size_t)j * blk_map;
+    // block spectra, once
+    for (int b = 0; b < nblk; b++) {
+        const int y0 = (b % nbh) * Bh, x0 = (b / nbh) * Bw;
+        const int hv = std::min(Bh, H - y0), wv = std::min(Bw, W - x0);
+        std::fill(blk.begin(), blk.end(), 0.f);
+        for (int f = 0; f < F; f++)
+            for (int x = 0; x < wv; x++)
+                memcpy(&blk[((size_t)f * Bw + x) * Bh], &data[((size_t)f * W + (x0 + x)) * H + y0], (size_t)hv * sizeof(float));
+        if ((rc = fftconv_plan_use_spectrum_buffer(sub, specs.p + (size_t)b * spec_elems, spec_elems * sizeof(c32)))) return finish(rc);
+        if ((rc = fftconv_plan_set_image(sub, blk.data(), FFTCONV_HOST))) return finish(rc);   // synchronous for host input
+    }
+    for (int k0 = 0; k0 < n; k0 += nc) {
+        const int nk = std::min(nc, n - k0);
+        if (hipMemsetAsync(big.p, 0, big_map * nk * sizeof(float), sub->stream) != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "hipMemsetAsync failed"));
+        for (int b = 0; b < nblk; b++) {
+            const int y0 = (b % nbh) * Bh, x0 = (b / nbh) * Bw;
+            if ((rc = fftconv_plan_use_spectrum_buffer(sub, specs.p + (size_t)b * spec_elems, spec_elems * sizeof(c32)))) return finish(rc);
+            if ((rc = fftconv_plan_mark_spectrum_valid(sub))) return finish(rc);
+            if ((rc = fftconv_plan_convolve(sub, nk, kernels + k0, kh + k0, kw + k0, FFTCONV_HOST, tptr.data(), FFTCONV_DEVICE))) return finish(rc);
+            hipError_t e = launch_add_window(big.p, FH, FW, big_map, y0, x0, tmp.p, g.fft_h, g.fft_w, blk_map, nk, sub->stream);
+            if (e != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "overlap-add failed: %s", hipGetErrorString(e)));
+        }
+        if (hipStreamSynchronize(sub->stream) != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "stream synchronisation failed"));
+        for (int j = 0; j < nk; j++)
+            if (hipMemcpy(out[k0 + j], big.p + (size_t)j * big_map, big_map * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+                return finish(fail(FFTCONV_ERR_HIP, "device-to-host copy failed"));
+    }
+    return finish(0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -644,6 +721,13 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
         return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
                     "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform", data_h, data_w,
                     feature_dim, max_kernel_h, max_kernel_w);
+    }
+    if (const char* e = getenv("FFTCONV_MAX_TRANSFORM")) {   // tests: make modest sizes take the block-wise path
+        const int lim = atoi(e);
+        if (lim > 0 && (p->g.Lh > lim || p->g.Lw > lim)) {
+            delete p;
+            return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "transform %dx%d exceeds FFTCONV_MAX_TRANSFORM=%d", data_h, data_w, lim);
+        }
     }
     p->gpu_id = gpu_id;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -961,7 +1045,13 @@ int fftconv_convolution_fft(const float* data, int data_h, int data_w, int featu
     if (fft_h) *fft_h = fft_size16(data_h + max_kernel_h - 1);
     if (fft_w) *fft_w = fft_size16(data_w + max_kernel_w - 1);
     fftconv_plan* p = nullptr;
-    if (int rc = fftconv_plan_create(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr)) return rc;
+    if (int rc = fftconv_plan_create(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr)) {
+        // too large for one single-pass plan: block-wise (overlap-add) over ordinary plans
+        if (rc == FFTCONV_ERR_UNSUPPORTED_SIZE && n_kernel > 0)
+            return tiled_convolution_fft(data, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, n_kernel, kernels, kernel_h,
+                                         kernel_w, gpu_id, out);
+        return rc;
+    }
     int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);
     if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, FFTCONV_HOST, out, FFTCONV_HOST);
     std::string keep = g_last_error;

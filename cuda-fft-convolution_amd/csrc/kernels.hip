@@ -49,6 +49,18 @@ __global__ void __launch_bounds__(256) k_flip_planes(const float* __restrict__ s
     }
 }
 
+// dst window += src window (overlap-add of block results into the full map): maps are column-major,
+// h contiguous; the source is clipped to the destination.
+__global__ void __launch_bounds__(256) k_add_window(float* __restrict__ dst, int dst_h, int dst_w, size_t dst_map_stride, int y0, int x0,
+                                                    const float* __restrict__ src, int src_h, int src_w, size_t src_map_stride) {
+    const int x = (int)blockIdx.x, map = (int)blockIdx.y;
+    if (x >= src_w || x0 + x >= dst_w) return;
+    const float* s = src + (size_t)map * src_map_stride + (size_t)x * src_h;
+    float* d = dst + (size_t)map * dst_map_stride + (size_t)(x0 + x) * dst_h + y0;
+    const int n = src_h < dst_h - y0 ? src_h : dst_h - y0;
+    for (int y = (int)threadIdx.x; y < n; y += (int)blockDim.x) d[y] += s[y];
+}
+
 // Raises the dynamic-LDS limit of a kernel once per device (the attribute is per device; a
 // process may drive several GPUs through different plans).
 template <class K>
@@ -394,6 +406,14 @@ hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, lon
     if (total <= 0) return hipSuccess;
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(k_flip_planes, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, src, dst, plane_elems, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_window(float* dst, int dst_h, int dst_w, size_t dst_map_stride, int y0, int x0, const float* src, int src_h,
+                             int src_w, size_t src_map_stride, int nmaps, hipStream_t s) {
+    if (nmaps <= 0 || src_w <= 0 || src_h <= 0 || y0 >= dst_h || x0 >= dst_w) return hipSuccess;
+    hipLaunchKernelGGL(k_add_window, dim3((unsigned)src_w, (unsigned)nmaps), dim3(256), 0, s, dst, dst_h, dst_w, dst_map_stride, y0, x0,
+                       src, src_h, src_w, src_map_stride);
     return hipGetLastError();
 }
 

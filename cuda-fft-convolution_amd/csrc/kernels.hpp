@@ -12,6 +12,9 @@ hipError_t kernels_init();
 
 // dst plane = src plane reversed (flip of a column-major kh x kw plane along both axes)
 hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, long nplanes, hipStream_t s);
+// dst[map][x0 + x][y0 + y] += src[map][x][y], clipped to the dst_h x dst_w window (column-major maps)
+hipError_t launch_add_window(float* dst, int dst_h, int dst_w, size_t dst_map_stride, int y0, int x0, const float* src, int src_h,
+                             int src_w, size_t src_map_stride, int nmaps, hipStream_t s);
 hipError_t launch_cols_r2c(const ColsR2CArgs& a, int tiles, int planes, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);

@@ -81,6 +81,10 @@ int fftconv_device_count(int *count);
  *                                                (the reference allocates them: :284-288)
  *   fft_h, fft_w                        out, nullable: the window size
  * Synchronous: results are complete on return, all device memory is released.
+ * Images whose padded size exceeds what one plan transforms in a single pass (the plan API
+ * reports FFTCONV_ERR_UNSUPPORTED_SIZE) are convolved block-wise here: overlap-add over
+ * ordinary plans, the block results summed on the device into the full FFT_H x FFT_W maps
+ * (kernels larger than MAX_KERNEL are rejected on that path).
  * ------------------------------------------------------------------------------------------ */
 int fftconv_convolution_fft(const float *data, int data_h, int data_w, int feature_dim,
                             int max_kernel_h, int max_kernel_w,

@@ -385,3 +385,51 @@ def test_flip_kernels_option_equals_flipping_by_hand(fc, oracle):
         plan.set_image(data2)
         m = plan.convolve([ks[0]])[0]
     assert np.unravel_index(np.argmax(m), m.shape) == (20 + kh - 1, 30 + kw - 1)
+
+
+# ---- block-wise (overlap-add) one-shot path for sizes beyond one plan ------------------------------
+
+@pytest.mark.parametrize("shape", [
+    (150, 40, 2, 9, 7, 3),      # h tiled only (FFTCONV_MAX_TRANSFORM = 64: blocks of 56 x W)
+    (40, 170, 1, 5, 11, 2),     # w tiled only
+    (130, 140, 2, 12, 10, 3),   # both: 3 x 3 blocks, ragged edges
+    (57, 57, 1, 9, 9, 1),       # one sample more than a block
+])
+def test_blockwise_one_shot_matches_oracle(fc, oracle, monkeypatch, shape):
+    """fftconv_convolution_fft falls back to overlap-add over ordinary plans when the padded size
+    does not fit one plan; FFTCONV_MAX_TRANSFORM (test hook) makes small problems take that path."""
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape))
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    if n > 1:
+        ks[1] = rng.standard_normal((kh - 2, kw - 1, F)).astype(np.float32)      # ragged cell
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    direct = fc.cudaConvolutionFFT(data, kh, kw, ks)
+    monkeypatch.setenv("FFTCONV_MAX_TRANSFORM", "64")
+    with pytest.raises(fc.FFTConvError) as ei:
+        fc.Plan(H, W, F, kh, kw)                       # the plan API itself reports the limit
+    assert ei.value.status == -5
+    got = fc.cudaConvolutionFFT(data, kh, kw, ks)
+    for g, d, r in zip(got, direct, ref):
+        assert g.shape == r.shape
+        assert util.rel_err(g, r) < TIGHT
+        assert util.rel_err(g, d) < TIGHT
+    # kernels beyond MAX_KERNEL cannot be folded block-wise: rejected, not wrapped
+    with pytest.raises(fc.FFTConvError) as ei:
+        fc.cudaConvolutionFFT(data, kh - 1, kw, ks)
+    assert ei.value.status == -4
+
+
+def test_blockwise_one_shot_beyond_the_single_pass_limit(fc, oracle):
+    """a really long dimension (W + kw - 1 = 21000 > the LDS-resident single pass): no test hook"""
+    rng = np.random.default_rng(21)
+    H, W, kh, kw = 24, 20990, 5, 11
+    data = rng.random((H, W, 1), dtype=np.float32)
+    ks = [rng.random((kh, kw, 1), dtype=np.float32) for _ in range(2)]
+    with pytest.raises(fc.FFTConvError) as ei:
+        fc.Plan(H, W, 1, kh, kw)
+    assert ei.value.status == -5
+    got = fc.cudaConvolutionFFT(data, kh, kw, ks)
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < TIGHT
