@@ -33,6 +33,8 @@ CONFIGS = {
     "cfg3": (4096, 4096, 1, 127, 127, 256, 3),
     "cfg4": (4096, 4096, 1, 63, 63, 128, 4),   # 1024 kernels over 8 GPUs
     "cfg5": (2048, 2048, 1, 63, 63, 64, 5),
+    # not a BASELINE config: the multi-feature form of the reference's demo (F planes summed per map)
+    "cfg3f4": (4096, 4096, 4, 127, 127, 64, 6),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
