@@ -35,6 +35,9 @@ CONFIGS = {
     "cfg5": (2048, 2048, 1, 63, 63, 64, 5),
     # not a BASELINE config: the multi-feature form of the reference's demo (F planes summed per map)
     "cfg3f4": (4096, 4096, 4, 127, 127, 64, 6),
+    "mid512": (512, 512, 1, 31, 31, 256, 7),   # not BASELINE configs: mid-sized images on the 576 / 768 / 1536 / 3072 transforms
+    "hd720": (720, 1280, 1, 31, 31, 128, 8),
+    "mid2900": (2900, 2900, 1, 63, 63, 64, 9),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 

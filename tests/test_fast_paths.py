@@ -20,7 +20,10 @@ BOTH_SHAPE = (4096, 4096, 1, 127, 127, 1)
 # cfg5 (2112), cfg4's 4160 window cropped from the 4224 transform, plus multi-feature / ragged
 OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 2048, 1, 63, 63, 1),
                 (4096, 300, 1, 63, 20, 1), (300, 4096, 2, 20, 63, 1), (1000, 1000, 3, 40, 50, 2),
-                (2000, 260, 1, 100, 29, 1), (250, 280, 2, 9, 9, 2)]
+                (2000, 260, 1, 100, 29, 1), (250, 280, 2, 9, 9, 2),
+                (512, 512, 1, 31, 31, 2), (540, 500, 2, 37, 40, 1),    # 576 x 576 transforms
+                (720, 640, 1, 21, 31, 2), (1280, 720, 1, 63, 47, 1), (1400, 1500, 2, 9, 11, 1),   # 768 / 1536
+                (3000, 200, 1, 65, 31, 1), (150, 2900, 1, 7, 150, 1)]   # 3072 in one dimension each
 VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent, pair_rows, cols_wide, fast_fwd)
     (0, 16, 0, 0, 1, 0, 1), (1, 16, 0, 0, 1, 0, 1), (1, 16, 0, 1, 1, 0, 0), (2, 16, 0, 0, 1, 0, 1), (2, 16, 0, 0, 1, 0, 0),
     (2, 16, 0, 0, 0, 0, 1), (2, 8, 0, 0, 1, 0, 1), (2, 8, 1, 0, 0, 0, 0), (2, 8, 2, 1, 0, 0, 1), (2, 16, 2, 1, 0, 0, 0),
