@@ -28,7 +28,8 @@ struct RowMultiState {
 // LINEAR (chosen by the launcher with fast_rows_multi_linear): see P5.
 inline bool fast_rows_multi_linear(const FastRowsArgs& g, int L, int m1) {
     const bool tiled = g.y_row_of != nullptr;
-    return g.wout >= L && (!tiled || (m1 & ((1 << g.y_tile_shift) - 1)) == 0);
+    (void)L;
+    return !tiled || (m1 & ((1 << g.y_tile_shift) - 1)) == 0;
 }
 
 template <class C, int NZ2, bool LINEAR, class Ctx>
@@ -192,7 +193,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             // LINEAR: the R1 outputs of a butterfly are m1 columns apart; when that is a whole number
             // of layout tiles (or the intermediate is row-major) and nothing is cropped, output a
             // sits at base + a * stride: a scalar base, one 32-bit add per store, no 64-bit tile
-            // arithmetic and no bounds compare (a fifth of this kernel's VALU instructions)
+            // arithmetic (a fifth of this kernel's VALU instructions; a cropped window adds a compare)
             if constexpr (LINEAR) {
                 char* yb = reinterpret_cast<char*>(ybase);
                 const unsigned stride_b = (unsigned)((tiled ? (m1 >> g.y_tile_shift) * g.y_tile_elems : m1) * (int)sizeof(c32));
@@ -214,10 +215,17 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         Dft<R1, +1>::run(v);
                         const int jo = tiled ? (j >> g.y_tile_shift) * g.y_tile_elems + (j & ((1 << g.y_tile_shift) - 1)) : j;
                         const unsigned off0 = (unsigned)(st.yoff[r] + jo) * (unsigned)sizeof(c32);
-                        static_for<0, R1>([&](auto a_) {
-                            constexpr int a = decltype(a_)::value;
-                            FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
-                        });
+                        if (g.wout >= L) {   // nothing cropped (uniform)
+                            static_for<0, R1>([&](auto a_) {
+                                constexpr int a = decltype(a_)::value;
+                                FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                            });
+                        } else {             // cropped window (cfg4: 4160 columns of the 4224 transform)
+                            static_for<0, R1>([&](auto a_) {
+                                constexpr int a = decltype(a_)::value;
+                                if (j + a * m1 < g.wout) FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                            });
+                        }
                     }
                     FC_SCHED_FENCE();
                 });
