@@ -1,7 +1,7 @@
 // fc_common.hpp -- shared host/device definitions for the FFT-convolution engine.
 //
 // Everything in the *.hpp files of this directory is written once and compiled twice:
-//   - by hipcc for gfx950 (the product: kernels.hip -> libfftconv.so), and
+//   - by hipcc for gfx950 (the product: kernels*.hip -> libfftconv.so), and
 //   - by g++ for the host inside tests/emu (a test-only executor that runs the very same
 //     workgroup bodies sequentially so the algorithm can be checked without a GPU).
 // The host build is test infrastructure; the product library contains no CPU compute path.

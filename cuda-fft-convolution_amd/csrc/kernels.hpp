@@ -1,4 +1,4 @@
-// kernels.hpp -- host-callable launchers of the HIP kernels (kernels.hip).
+// kernels.hpp -- host-callable launchers of the HIP kernels (kernels*.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -14,7 +14,7 @@
 // Rows i of the spectra are never reordered: every row is processed independently by the
 // w-passes and the h-passes consume exactly the order they produce.
 //
-// Each body is a template over a context {tid, nthreads, sync()}; kernels.hip instantiates it
+// Each body is a template over a context {tid, nthreads, sync()}; kernels*.hip instantiate it
 // with the HIP thread/barrier, tests/emu with a sequential host context.
 #pragma once
 #include "fc_common.hpp"

@@ -1,0 +1,50 @@
+// kernels_rows_multi.hip -- the multi-map spectral-row kernel (fast_rows_multi.hpp), the default for F = 1
+// (one of the kernels_*.hip translation units; see kernels_common.hpp).
+#include "kernels_common.hpp"
+
+namespace fc {
+namespace {
+
+template <class Cfg, int NZ2, bool LINEAR>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_multi(FastRowsArgs a, int rows, int kernels, int per_wg) {
+    const int group = (int)blockIdx.x;
+    const int kernel0 = (int)blockIdx.y * per_wg;
+    const int nk = kernels - kernel0 < per_wg ? kernels - kernel0 : per_wg;
+    DevPhaseCtx<RowMultiState<Cfg>> ctx;
+    fast_rows_multi_body<Cfg, NZ2, LINEAR>(ctx, reinterpret_cast<c32*>(fc_smem), a, group, kernel0, nk, rows);
+}
+
+struct FastRowsMultiLauncher {
+    const FastRowsArgs& a;
+    int rows, kernels, per_wg;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg, int NZ2>
+    void go() {
+        if (fast_rows_multi_linear(a, Cfg::L, Cfg::m1)) launch<Cfg, NZ2, true>();
+        else launch<Cfg, NZ2, false>();
+    }
+    template <class Cfg, int NZ2, bool LINEAR>
+    void launch() {
+        static unsigned long long attr_mask = 0;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        err = ensure_lds_attr(k_fast_rows_multi<Cfg, NZ2, LINEAR>, attr_mask);
+        if (err != hipSuccess) return;
+        const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
+        const dim3 grid(groups, (kernels + per_wg - 1) / per_wg);
+        hipLaunchKernelGGL((k_fast_rows_multi<Cfg, NZ2, LINEAR>), grid, dim3(Cfg::NT), lds, s, a, rows, kernels, per_wg);
+        err = hipGetLastError();
+    }
+};
+
+}  // namespace
+
+hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s) {
+    if (rows <= 0 || kernels <= 0) return hipSuccess;
+    if (a.F != 1 || kernels_per_wg < 1) return hipErrorInvalidValue;
+    FastRowsMultiLauncher l{a, rows, kernels, kernels_per_wg, s};
+    if (!fast_rows_dispatch(L, nz2, l)) return hipErrorInvalidValue;
+    return l.err;
+}
+
+}  // namespace fc

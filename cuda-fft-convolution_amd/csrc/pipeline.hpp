@@ -53,7 +53,7 @@ struct Geometry {
     int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
     int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
     int y_row_order = 0;       // see make_fast_cols_tables
-    int rows_wg_order = 0;     // workgroup order of the fast row kernel (kernels.hip: k_fast_rows); 1, 2 measured equal
+    int rows_wg_order = 0;     // workgroup order of the fast row kernel (kernels_rows.hip: k_fast_rows); F = 1: 1, 2 measured equal, F > 1: 2 by default
     // maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1): -1 = chosen per
     // launch (rows_group_for), 0 / 1 = plain one-map kernel, > 1 = fixed (A/B runs)
     int rows_group = -1;
