@@ -21,6 +21,17 @@
 #define FC_COLS_DBG 0   // timing experiments only (wrong results): 1 skip pair pass, 2 no barriers between stages, 4 no gather loads, 8 no stores, 16 contiguous gather addresses (tiled mode)
 #endif
 
+#ifndef FC_COLS_TIMELINE
+#define FC_COLS_TIMELINE 0     // 1: workgroup 0 stamps the 100 MHz wall clock at every phase boundary (tools/cols_timeline.py)
+#endif
+#if FC_COLS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
+#define FC_COLS_STAMP(slot) do { if (wg == 0 && threadIdx.x == 0 && g.timeline && it < 16) g.timeline[it * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define FC_COLS_STAMP(slot) ((void)0)
+#endif
+#ifndef FC_COLS_SPLIT_GATHER
+#define FC_COLS_SPLIT_GATHER 1   // 0: A/B, the whole gather of the next tile issued at the start of the tile
+#endif
 #ifndef FC_COLS_NO_PREWAIT
 #define FC_COLS_NO_PREWAIT 0   // 1: A/B, without the vmcnt(0) ahead of the store burst
 #endif
@@ -80,6 +91,7 @@ struct FastColsArgs {
     const c32* tw1;          // w_M^j, j < m1
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
     const PairEntry* pairs;  // NPE entries: [0] DC/Nyquist, [k] pair (k, M-k), [M/2] middle (w = w_N^k)
+    unsigned long long* timeline;  // FC_COLS_TIMELINE builds only: per-phase wall-clock stamps of workgroup 0 (else unused)
 };
 
 template <class C>
@@ -134,13 +146,19 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     };
     const int first_tile = tile_of(0);
 
-    auto issue_gather = [&](int t, State& st, int tile) {
+    // part: 0 = the whole gather; 1 / 2 (mode 3) = its first / second half of rounds -- a CU cannot
+    // keep a whole tile (135 KB) of loads in flight, so issuing it in one go stalls the waves in
+    // the issue itself; the second half is issued one phase later, while the first drains
+    auto issue_gather = [&](int t, State& st, int tile, auto part_) {
+        constexpr int part = decltype(part_)::value;
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
         if constexpr (PLAND) {   // rows 2p, 2p+1 = bins (p, M-p); one thread takes both for two columns
             const int tw = 1 << g.y_tile_shift;
             const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 >> g.y_tile_shift) * g.y_tile_elems + (w0 & (tw - 1));
-            static_for<0, State::RNDU>([&](auto r_) {
+            constexpr int RH = (State::RNDU + 1) / 2;
+            constexpr int RB = (part == 2) ? RH : 0, RE = (part == 1) ? RH : State::RNDU;
+            static_for<RB, RE>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int e = t + NT * r;
                 if (e < State::NPU) {
@@ -247,7 +265,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             constexpr int r = decltype(r_)::value;
             st.off[r] = (PRE || TILED) ? g.lpos[(t + NT * r) / T2] : g.rowoff[(t + NT * r) / T2];
         });
-        if (first_tile < g.ntiles) issue_gather(t, st, first_tile);
+        if (first_tile < g.ntiles) issue_gather(t, st, first_tile, IC<0>{});
     });
     // (the landing of mode 3 reads the tables written above: it needs the barrier in between)
     if (first_tile < g.ntiles) ctx.phase([&](int t, State& st) { land_gather(t, st); });
@@ -258,14 +276,15 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
         const int next = tile_of(it + 1);
+        FC_COLS_STAMP(0);
 
         // C1: issue the next tile's gather (lands after C4), then merge the half spectrum of
         // this tile into the packed complex sequence, in place (table driven)
         if constexpr (PRE || PLAND) ctx.phase_nosync([&](int t, State& st) {
-            if (next < g.ntiles) issue_gather(t, st, next);
+            if (next < g.ntiles) issue_gather(t, st, next, IC<(PLAND && FC_COLS_SPLIT_GATHER) ? 1 : 0>{});
         });
         else ctx.phase([&](int t, State& st) {
-            if (next < g.ntiles) issue_gather(t, st, next);
+            if (next < g.ntiles) issue_gather(t, st, next, IC<0>{});
             if constexpr (!(FC_COLS_DBG & 1))
             FC_NOUNROLL
             for (int r = 0; r < C::RNDP; r++) {   // not unrolled: keeps the register footprint small
@@ -298,6 +317,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             }
         });
 
+        FC_COLS_STAMP(1);
         // C2: inverse stage 3 (radix R3 on contiguous runs), one butterfly per thread
         ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
             const int col = t / C::NB3, q = t % C::NB3;
@@ -319,6 +339,10 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             });
         });
 
+        FC_COLS_STAMP(2);
+        if constexpr (PLAND && FC_COLS_SPLIT_GATHER) ctx.phase_nosync([&](int t, State& st) {
+            if (next < g.ntiles) issue_gather(t, st, next, IC<2>{});
+        });
         // C3: inverse stage 2 (radix R2, sub-length R3)
         ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
@@ -343,6 +367,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             });
         });
 
+        FC_COLS_STAMP(3);
         // C4: inverse stage 1 straight to the map: out[w][2n], out[w][2n+1] = re, im of z[n]
         float* out = g.out + (size_t)kernel * g.out_kernel_stride;
         const int nout = g.fft_h >> 1;   // complex pairs per output column
@@ -352,6 +377,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             // memory counter now, so that landing it does not wait for the stores below
             FC_WAIT_VMEM();
 #endif
+            FC_COLS_STAMP(4);
             FC_NOUNROLL
             for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the prefetched tile stays in registers
                 const int idx = t + NT * r;
@@ -377,8 +403,10 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             }
         });
 
+        FC_COLS_STAMP(5);
         // C5: the prefetched tile lands in LDS
         if (next < g.ntiles) ctx.phase([&](int t, State& st) { land_gather(t, st); });
+        FC_COLS_STAMP(6);
     }
 }
 

@@ -250,6 +250,8 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.y_pair_rows = g.y_pair_rows() ? 1 : 0;
     a.y_precombined = g.y_pre() ? 1 : 0; a.lpos = g.y_pre() ? d.fc_lpos : d.fc_tile_lpos;
     if (g.y_pre()) a.y_tile_elems = g.M * 8;
+    a.timeline = nullptr;
+    if (const char* e = getenv("FFTCONV_COLS_TIMELINE_PTR")) a.timeline = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));   // FC_COLS_TIMELINE builds
     return a;
 }
 
