@@ -25,7 +25,13 @@
 #define FC_COLS_TIMELINE 0     // 1: workgroup 0 stamps the 100 MHz wall clock at every phase boundary (tools/cols_timeline.py)
 #endif
 #if FC_COLS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
-#define FC_COLS_STAMP(slot) do { if (wg == 0 && threadIdx.x == 0 && g.timeline && it < 16) g.timeline[it * 8 + (slot)] = wall_clock64(); } while (0)
+#ifndef FC_COLS_TIMELINE_BASE
+#define FC_COLS_TIMELINE_BASE 0   // first tile (of workgroup FC_COLS_TIMELINE_WG) that is stamped; 16 tiles are
+#endif
+#ifndef FC_COLS_TIMELINE_WG
+#define FC_COLS_TIMELINE_WG 0
+#endif
+#define FC_COLS_STAMP(slot) do { if (wg == FC_COLS_TIMELINE_WG && threadIdx.x == 0 && g.timeline && it >= FC_COLS_TIMELINE_BASE && it < FC_COLS_TIMELINE_BASE + 16) g.timeline[(it - FC_COLS_TIMELINE_BASE) * 8 + (slot)] = wall_clock64(); } while (0)
 #else
 #define FC_COLS_STAMP(slot) ((void)0)
 #endif
