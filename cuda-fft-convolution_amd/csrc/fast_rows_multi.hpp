@@ -15,6 +15,21 @@
 #pragma once
 #include "fast_rows.hpp"
 
+#ifndef FC_ROWS_NO_FOLD
+#define FC_ROWS_NO_FOLD 0      // 1: A/B, forward stage 1 as a phase of its own for every map
+#endif
+#ifndef FC_ROWS_TIMELINE
+#define FC_ROWS_TIMELINE 0     // 1: one workgroup stamps the 100 MHz wall clock at every phase boundary (tools/rows_timeline.py)
+#endif
+#ifndef FC_ROWS_TIMELINE_WG
+#define FC_ROWS_TIMELINE_WG 1000
+#endif
+#if FC_ROWS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
+#define FC_ROWS_STAMP(slot) do { if (group == FC_ROWS_TIMELINE_WG && kernel0 == 0 && threadIdx.x == 0 && g.row_seq && m < 16) reinterpret_cast<unsigned long long*>(const_cast<int*>(g.row_seq))[m * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define FC_ROWS_STAMP(slot) ((void)0)
+#endif
+
 namespace fc {
 
 template <class C>
@@ -40,6 +55,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
     const int kw = g.kw;
     const int row0 = group * RPW;
     const bool tiled = g.y_row_of != nullptr;
+    constexpr bool FOLD = !(FC_ROWS_NO_FOLD);
 
     auto load_x = [&](int t, State& st, int kernel) {
         const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride;
@@ -83,9 +99,15 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
 
     for (int m = 0; m < nk; m++) {
         const int kernel = kernel0 + m;
+        FC_ROWS_STAMP(0);
 
-        // P1: forward stage 1, pruned (one non-zero input per butterfly)
-        ctx.phase([&](int t, State& st) {
+        // P1: forward stage 1, pruned (one non-zero input per butterfly) -- as a phase of its own
+        // only for the first map of the walk; for the others it is folded into the previous map's P5
+        // (FOLD): the thread that has just read the R1 LDS cells of butterfly j for the inverse
+        // stage 1 is the only one that ever touches them, so it writes the next map's stage-1
+        // outputs into them right away, with the twiddle chain it has at hand -- one phase and one
+        // barrier fewer per map
+        if (!FOLD || m == 0) ctx.phase([&](int t, State& st) {
             static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int u = t + NT * r;
@@ -106,6 +128,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         // the next kernel's row flies during P2..P5
         if (m + 1 < nk) ctx.phase_nosync([&](int t, State& st) { load_x(t, st, kernel + 1); });
 
+        FC_ROWS_STAMP(1);
         // P2: forward stage 2
         ctx.phase([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
@@ -131,6 +154,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             });
         });
 
+        FC_ROWS_STAMP(2);
         // P3: forward stage 3, product with the image spectrum (registers), inverse stage 3
         ctx.phase([&](int t, State& st) {
             const int rr = t / C::NB3, q = t - rr * C::NB3;
@@ -159,6 +183,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             }
         });
 
+        FC_ROWS_STAMP(3);
         // P4: inverse stage 2
         ctx.phase([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
@@ -183,6 +208,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             });
         });
 
+        FC_ROWS_STAMP(4);
         // P5: inverse stage 1 straight to global memory; the barrier protects the LDS row
         // against the next map's P1
         c32* ybase = g.Y + (size_t)kernel * g.y_kernel_stride;
@@ -226,6 +252,14 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                                 if (j + a * m1 < g.wout) FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
                             });
                         }
+                        if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read
+                            c32* wbuf = lds + rr * L;
+                            wbuf[j] = st.x[r];
+                            static_for<1, R1>([&](auto c_) {
+                                constexpr int c = decltype(c_)::value;
+                                wbuf[c * m1 + j] = cmul(st.x[r], p[c]);
+                            });
+                        }
                     }
                     FC_SCHED_FENCE();
                 });
@@ -256,10 +290,19 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                             else FC_STREAM_STORE(&yrow[w], v[a]);
                         }
                     });
+                    if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read
+                        c32* wbuf = lds + rr * L;
+                        wbuf[j] = st.x[r];
+                        static_for<1, R1>([&](auto c_) {
+                            constexpr int c = decltype(c_)::value;
+                            wbuf[c * m1 + j] = cmul(st.x[r], p[c]);
+                        });
+                    }
                 }
                 FC_SCHED_FENCE();
             });
         });
+        FC_ROWS_STAMP(5);
     }
 }
 

@@ -226,6 +226,7 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.y_row_of = g.y_tiled() ? (g.use_wide() ? d.cw_tile_row_of : (g.y_pair_rows() ? d.fc_pair_row_of : d.fc_tile_row_of)) : nullptr;
     a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
     a.row_seq = (g.rows_persistent && g.y_pair_rows()) ? d.fc_pair_row_seq : nullptr;
+    if (const char* e = getenv("FFTCONV_ROWS_TIMELINE_PTR")) a.row_seq = reinterpret_cast<const int*>(strtoull(e, nullptr, 0));   // FC_ROWS_TIMELINE builds (the multi-map kernel does not use row_seq)
     return a;
 }
 
