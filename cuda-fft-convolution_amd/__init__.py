@@ -45,6 +45,7 @@ class PlanInfo(ctypes.Structure):
         ("gpu_id", ctypes.c_int), ("exact_window", ctypes.c_int),
         ("spectrum_bytes", ctypes.c_size_t), ("map_bytes", ctypes.c_size_t),
         ("workspace_bytes", ctypes.c_size_t),
+        ("out_h", ctypes.c_int), ("out_w", ctypes.c_int), ("out_map_bytes", ctypes.c_size_t),
     ]
 
 
@@ -263,16 +264,18 @@ class Plan:
                 raise FFTConvError(-3, "Kernel and Data must have the same number of features and kernel "
                                        "size should be smaller than data size")
         n = len(ks)
+        _check(self._lib.fftconv_plan_get_info(self._h, ctypes.byref(self.info)))   # out_h / out_w follow "output_region"
+        oh, ow = self.info.out_h, self.info.out_w
         if out is None:
-            outs = [np.empty((self.info.fft_h, self.info.fft_w), dtype=np.float32, order="F") for _ in range(n)]
+            outs = [np.empty((oh, ow), dtype=np.float32, order="F") for _ in range(n)]
         else:
             outs = list(out)
             if len(outs) != n:
                 raise FFTConvError(-1, "out must hold one buffer per kernel")
             for o in outs:
-                if (o.dtype != np.float32 or o.shape != (self.info.fft_h, self.info.fft_w)
+                if (o.dtype != np.float32 or o.shape != (oh, ow)
                         or not o.flags.f_contiguous or not o.flags.writeable):
-                    raise FFTConvError(-1, "out buffers must be writable FFT_H x FFT_W float32 in Fortran order")
+                    raise FFTConvError(-1, "out buffers must be writable out_h x out_w float32 in Fortran order")
         optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
         _check(self._lib.fftconv_plan_convolve(self._h, n, kptr, kh, kw, HOST, optr, HOST))
         return outs
@@ -298,6 +301,7 @@ class Plan:
 
     def set_option(self, name, value):
         _check(self._lib.fftconv_plan_set_option(self._h, name.encode(), int(value)))
+        _check(self._lib.fftconv_plan_get_info(self._h, ctypes.byref(self.info)))
 
     def profile(self, reset=True):
         pr = Profile()

@@ -245,6 +245,12 @@ struct fftconv_plan {
     DevBuf<float> K;   // packed kernels staged on the device
     DevBuf<float> KF;  // flipped copy of the current chunk of kernels ("flip_kernels")
     long opt_flip_kernels = 0;
+    // "output_region": which part of the padded window a map holds (MAX_KERNEL sizes K):
+    // 0 window FFT_H x FFT_W (the reference), 1 full (DATA + K - 1), 2 same (DATA, centred), 3 valid (DATA - K + 1)
+    long opt_region = 0;
+    int out_h = 0, out_w = 0, off_h = 0, off_w = 0;
+    DevBuf<float> OC;  // cropped maps staged for the copy-out
+    size_t out_elems() const { return opt_region ? (size_t)out_h * out_w : g.map_elems(); }
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
     DevBuf<c32> fr_tw1, fr_tw2;
@@ -323,7 +329,7 @@ struct fftconv_plan {
         pending.clear();
         pool.clear();
         tw_m.release(); tw_w.release(); pairs.release();
-        S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); I.release();
+        S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); OC.release(); I.release();
         fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release(); fc_pair_row_of.release(); fc_pair_row_seq.release();
         cw_tw3.release(); cw_twA.release(); cw_twF.release(); cw_wh.release(); cw_wl.release();
@@ -389,7 +395,7 @@ int check_kernel_size(const fftconv_plan* p, int kh, int kw) {
 // pinned ring + copy stream + host copy threads of the host-output path, sized for this plan's maps
 int ring_ensure(fftconv_plan* p) {
     if (p->ring) return 0;
-    const size_t map_bytes = p->g.map_elems() * sizeof(float);
+    const size_t map_bytes = p->out_elems() * sizeof(float);
     size_t chunk = p->opt_host_chunk_kb > 0 ? (size_t)p->opt_host_chunk_kb << 10 : (size_t)8 << 20;
     chunk = std::min(chunk, (map_bytes + 4095) / 4096 * 4096);
     chunk = std::max<size_t>(4096, chunk / 4096 * 4096);
@@ -441,17 +447,17 @@ bool caller_pinned(const void* ptr) {
 // queue the copy-out of the maps [first, first + count) that sit in staging buffer `buf`
 int ring_drain(fftconv_plan* p, const Sink& sink, int first, int count, int buf, const float* staging) {
     HostRing* r = p->ring;
-    const size_t map_bytes = p->g.map_elems() * sizeof(float);
+    const size_t map_bytes = p->out_elems() * sizeof(float);
     if (r->nslots == 0) {   // direct: whole maps, one per host thread at a time
         for (int j = 0; j < count; j++)
-            r->submit_direct(reinterpret_cast<const char*>(staging + (size_t)j * p->g.map_elems()),
+            r->submit_direct(reinterpret_cast<const char*>(staging + (size_t)j * p->out_elems()),
                              reinterpret_cast<char*>(sink.ptrs[first + j]), map_bytes, buf);
         return 0;
     }
     HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->compute_done[buf], 0));
     for (int j = 0; j < count; j++) {
         char* dst = reinterpret_cast<char*>(sink.ptrs[first + j]);
-        const char* src = reinterpret_cast<const char*>(staging + (size_t)j * p->g.map_elems());
+        const char* src = reinterpret_cast<const char*>(staging + (size_t)j * p->out_elems());
         if (caller_pinned(dst)) {
             HIP_TRY(hipMemcpyAsync(dst, src, map_bytes, hipMemcpyDeviceToHost, r->copy_stream));
             continue;
@@ -508,8 +514,15 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     const bool staged = (sink.packed == nullptr);
     // host output: two staging buffers, the copy-out of batch b overlaps the compute of batch b + 1
     const bool streamed = staged && sink.location == FFTCONV_HOST && p->opt_host_stream != 0;
+    // a region other than the whole window: the output kernel writes the window into O, a crop
+    // kernel compacts the region into the destination (the caller's packed buffer or the staging OC)
+    const bool cropped = p->opt_region != 0;
+    const size_t oe = p->out_elems();
+    DevBuf<float>& stage = cropped ? p->OC : p->O;
+    if (cropped)
+        if (int rc = p->O.ensure(g.map_elems() * nbY)) return rc;
     if (staged)
-        if (int rc = p->O.ensure(g.map_elems() * nbY * (streamed ? 2 : 1))) return rc;
+        if (int rc = stage.ensure(oe * nbY * (streamed ? 2 : 1))) return rc;
     if (streamed)
         if (int rc = ring_ensure(p)) return rc;
     int batch = 0;
@@ -541,7 +554,8 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
             }
             if (int rc = p->prof_end()) return rc;
             const int buf = streamed ? (batch & 1) : 0;
-            float* obase = staged ? p->O.p + (size_t)buf * nbY * g.map_elems() : sink.packed + (size_t)(a0 + y0) * g.map_elems();
+            float* dest = staged ? stage.p + (size_t)buf * nbY * oe : sink.packed + (size_t)(a0 + y0) * oe;   // where the maps of this batch go
+            float* obase = cropped ? p->O.p : dest;                                                            // where the output kernel writes
             if (streamed && batch >= 2) {   // staging buffer `buf` still holds batch - 2 until its copy-out is over
                 if (p->ring->nslots == 0) p->ring->wait_staging_free(buf);
                 else HIP_TRY(hipStreamWaitEvent(p->stream, p->ring->copy_done[buf], 0));
@@ -558,16 +572,18 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
                 HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));
             }
             if (int rc = p->prof_end()) return rc;
+            if (cropped)
+                HIP_TRY(launch_crop_maps(p->O.p, g.fft_h, g.map_elems(), dest, p->out_h, p->out_w, oe, p->off_h, p->off_w, ny, p->stream));
             if (streamed) {
                 HIP_TRY(hipEventRecord(p->ring->compute_done[buf], p->stream));
                 if (prev.valid)
-                    if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, p->O.p + (size_t)prev.buf * nbY * g.map_elems())) return rc;
+                    if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, stage.p + (size_t)prev.buf * nbY * oe)) return rc;
                 prev.valid = true; prev.first = a0 + y0; prev.count = ny; prev.buf = buf;
                 batch++;
             } else if (staged) {
                 for (int j = 0; j < ny; j++) {
                     float* dst = sink.ptrs[a0 + y0 + j];
-                    HIP_TRY(hipMemcpyAsync(dst, p->O.p + (size_t)j * g.map_elems(), g.map_elems() * sizeof(float),
+                    HIP_TRY(hipMemcpyAsync(dst, stage.p + (size_t)j * oe, oe * sizeof(float),
                                            sink.location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                                            p->stream));
                 }
@@ -577,7 +593,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     }
     if (streamed) {
         if (prev.valid)
-            if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, p->O.p + (size_t)prev.buf * nbY * g.map_elems())) return rc;
+            if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, stage.p + (size_t)prev.buf * nbY * oe)) return rc;
         hipError_t e = p->ring->wait_idle();
         if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "host-output copy failed: %s", hipGetErrorString(e));
     }
@@ -850,6 +866,9 @@ int fftconv_plan_get_info(const fftconv_plan* plan, fftconv_plan_info* info) {
     info->exact_window = g.exact_window ? 1 : 0;
     info->spectrum_bytes = g.spectrum_elems() * sizeof(c32);
     info->map_bytes = g.map_elems() * sizeof(float);
+    info->out_h = plan->opt_region ? plan->out_h : g.fft_h;
+    info->out_w = plan->opt_region ? plan->out_w : g.fft_w;
+    info->out_map_bytes = plan->out_elems() * sizeof(float);
     info->workspace_bytes = plan->A.bytes() + plan->Y.bytes() + plan->K.bytes() + plan->O.bytes() + plan->I.bytes();
     return 0;
 }
@@ -1001,6 +1020,20 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "output_region")) {
+        const Geometry& g = plan->g;
+        int oh = g.fft_h, ow = g.fft_w, fh = 0, fw = 0;
+        if (value == 1) { oh = g.H + g.max_kh - 1; ow = g.W + g.max_kw - 1; }
+        else if (value == 2) { oh = g.H; ow = g.W; fh = (g.max_kh - 1) / 2; fw = (g.max_kw - 1) / 2; }
+        else if (value == 3) { oh = g.H - g.max_kh + 1; ow = g.W - g.max_kw + 1; fh = g.max_kh - 1; fw = g.max_kw - 1; }
+        else if (value != 0) return fail(FFTCONV_ERR_INVALID_ARG, "output_region is 0 (window), 1 (full), 2 (same) or 3 (valid)");
+        if (oh < 1 || ow < 1) return fail(FFTCONV_ERR_INVALID_ARG, "output_region %ld is empty for %dx%d data and %dx%d kernels", value, g.H, g.W, g.max_kh, g.max_kw);
+        if (int rc = use_device(plan)) return rc;
+        HIP_TRY(hipStreamSynchronize(plan->stream));
+        plan->release_ring();          // sized for the map bytes
+        plan->opt_region = value; plan->out_h = oh; plan->out_w = ow; plan->off_h = fh; plan->off_w = fw;
+        return 0;
+    }
     if (!strcmp(name, "flip_kernels")) { plan->opt_flip_kernels = value != 0; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "host_stream") || !strcmp(name, "host_threads") || !strcmp(name, "host_chunk_kb") || !strcmp(name, "host_slots")) {
         if (value < 0 || value > (1 << 20)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);

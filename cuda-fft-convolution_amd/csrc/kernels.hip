@@ -58,6 +58,16 @@ __global__ void __launch_bounds__(256) k_add_window(float* __restrict__ dst, int
     for (int y = (int)threadIdx.x; y < n; y += (int)blockDim.x) d[y] += s[y];
 }
 
+// dst map (dst_h x dst_w, contiguous) = the window [off_h, off_h + dst_h) x [off_w, off_w + dst_w) of the
+// src map (src_h rows per column): the "full" / "same" / "valid" regions of the padded window
+__global__ void __launch_bounds__(256) k_crop_maps(const float* __restrict__ src, int src_h, size_t src_map_stride, float* __restrict__ dst,
+                                                   int dst_h, int dst_w, size_t dst_map_stride, int off_h, int off_w) {
+    const int x = (int)blockIdx.x, map = (int)blockIdx.y;
+    const float* s = src + (size_t)map * src_map_stride + (size_t)(off_w + x) * src_h + off_h;
+    float* d = dst + (size_t)map * dst_map_stride + (size_t)x * dst_h;
+    for (int y = (int)threadIdx.x; y < dst_h; y += (int)blockDim.x) d[y] = s[y];
+}
+
 }  // namespace
 
 hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, long nplanes, hipStream_t s) {
@@ -73,6 +83,14 @@ hipError_t launch_add_window(float* dst, int dst_h, int dst_w, size_t dst_map_st
     if (nmaps <= 0 || src_w <= 0 || src_h <= 0 || y0 >= dst_h || x0 >= dst_w) return hipSuccess;
     hipLaunchKernelGGL(k_add_window, dim3((unsigned)src_w, (unsigned)nmaps), dim3(256), 0, s, dst, dst_h, dst_w, dst_map_stride, y0, x0,
                        src, src_h, src_w, src_map_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_maps(const float* src, int src_h, size_t src_map_stride, float* dst, int dst_h, int dst_w, size_t dst_map_stride,
+                            int off_h, int off_w, int nmaps, hipStream_t s) {
+    if (nmaps <= 0 || dst_h <= 0 || dst_w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_crop_maps, dim3((unsigned)dst_w, (unsigned)nmaps), dim3(256), 0, s, src, src_h, src_map_stride, dst, dst_h, dst_w,
+                       dst_map_stride, off_h, off_w);
     return hipGetLastError();
 }
 

@@ -15,6 +15,9 @@ hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, lon
 // dst[map][x0 + x][y0 + y] += src[map][x][y], clipped to the dst_h x dst_w window (column-major maps)
 hipError_t launch_add_window(float* dst, int dst_h, int dst_w, size_t dst_map_stride, int y0, int x0, const float* src, int src_h,
                              int src_w, size_t src_map_stride, int nmaps, hipStream_t s);
+// dst[map] (dst_h x dst_w, contiguous) = window of src[map] at (off_h, off_w); src has src_h rows per column
+hipError_t launch_crop_maps(const float* src, int src_h, size_t src_map_stride, float* dst, int dst_h, int dst_w, size_t dst_map_stride,
+                            int off_h, int off_w, int nmaps, hipStream_t s);
 hipError_t launch_cols_r2c(const ColsR2CArgs& a, int tiles, int planes, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);

@@ -117,6 +117,8 @@ typedef struct fftconv_plan_info {
     size_t spectrum_bytes;     /* size of the image spectrum buffer */
     size_t map_bytes;          /* fft_h * fft_w * sizeof(float) */
     size_t workspace_bytes;    /* device scratch currently held */
+    int out_h, out_w;          /* size of every result map: the window, or the "output_region" chosen */
+    size_t out_map_bytes;      /* out_h * out_w * sizeof(float) */
 } fftconv_plan_info;
 
 /* hip_stream: hipStream_t to run on (NULL = the device's default stream). */
@@ -184,6 +186,12 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             batch; 1 (default) = host threads of the plan copy batch b straight into the caller's
  *             buffers while batch b+1 is computed; 2 = through a ring of pinned chunks),
  *          "host_threads", "host_chunk_kb", "host_slots" (shape of that machinery, 0 = auto),
+ *          "output_region" (which part of the padded window a result map holds, for the plan's
+ *             MAX_KERNEL sizes K: 0 (default) the whole FFT_H x FFT_W window as the reference
+ *             returns it; 1 "full" = the linear convolution, (DATA + K - 1), what the demo crops by
+ *             hand (demoCudaConvolutionFFT.m:149); 2 "same" = DATA-sized, centred; 3 "valid" =
+ *             DATA - K + 1, no zero padding involved.  Result buffers then hold out_h x out_w
+ *             floats (fftconv_plan_get_info)),
  *          "flip_kernels" (1: every kernel is flipped along h and w on the device before it is
  *             transformed, i.e. the plan correlates -- the "Flip Kernel (Required)" step of
  *             demoCudaConvolutionFFT.m:63-69 done here instead of in MATLAB; the reference keeps a

@@ -433,3 +433,51 @@ def test_blockwise_one_shot_beyond_the_single_pass_limit(fc, oracle):
     got = fc.cudaConvolutionFFT(data, kh, kw, ks)
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < TIGHT
+
+
+# ---- output_region: full / same / valid parts of the padded window ---------------------------------
+
+@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4, 3), (300, 260, 1, 31, 17, 5), (1024, 1024, 1, 63, 63, 2)])
+def test_output_regions_match_slices_of_the_window(fc, oracle, shape):
+    """the demo crops the linear convolution out of the window by hand
+    (demoCudaConvolutionFFT.m:149: cvg(1:n+cn-1, 1:m+cm-1)); "output_region" returns that ("full"),
+    the data-sized centred part ("same") or the part free of zero padding ("valid") directly"""
+    torch = pytest.importorskip("torch")
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    regions = {1: (H + kh - 1, W + kw - 1, 0, 0), 2: (H, W, (kh - 1) // 2, (kw - 1) // 2), 3: (H - kh + 1, W - kw + 1, kh - 1, kw - 1)}
+    with fc.Plan(H, W, F, kh, kw) as plan:
+        plan.set_image(data)
+        for region, (oh, ow, fh, fw) in regions.items():
+            plan.set_option("output_region", region)
+            assert (plan.info.out_h, plan.info.out_w) == (oh, ow) and plan.info.out_map_bytes == oh * ow * 4
+            for mode in (1, 0):                      # streamed and blocking copy-out
+                plan.set_option("host_stream", mode)
+                got = plan.convolve(ks)
+                for g, r in zip(got, ref):
+                    assert g.shape == (oh, ow)
+                    assert util.rel_err(g, r[fh:fh + oh, fw:fw + ow]) < TIGHT * max(1.0, np.abs(r).max() / np.abs(r[fh:fh + oh, fw:fw + ow]).max())
+            # packed device path: [n][out_w][out_h]
+            kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in ks]))).cuda()   # [n][F][kw][kh]
+            od = torch.full((n, ow, oh), float("nan"), dtype=torch.float32, device="cuda")
+            plan.convolve_packed_device(n, kd.data_ptr(), kh, kw, od.data_ptr())
+            plan.synchronize()
+            for j, r in enumerate(ref):
+                assert np.array_equal(od[j].cpu().numpy().T, got[j])
+        plan.set_option("output_region", 0)
+        assert (plan.info.out_h, plan.info.out_w) == (plan.info.fft_h, plan.info.fft_w)
+        back = plan.convolve(ks[:1])[0]
+        assert util.rel_err(back, ref[0]) < TIGHT
+
+
+def test_output_region_rejects_empty_and_unknown(fc):
+    with fc.Plan(20, 20, 1, 31, 5) as plan:
+        with pytest.raises(fc.FFTConvError):
+            plan.set_option("output_region", 3)      # valid region empty: kernel taller than the data
+        with pytest.raises(fc.FFTConvError):
+            plan.set_option("output_region", 7)
+        plan.set_option("output_region", 1)
+        assert (plan.info.out_h, plan.info.out_w) == (50, 24)
