@@ -50,9 +50,13 @@
 #define FC_STREAM_STORE(ptr, val) (*(ptr) = (val))
 #endif
 
-// Streaming 16-byte load (data read exactly once): FC_NT_LOADS=0 restores plain loads for A/B runs.
+// 16-byte load of data this kernel reads once.  FC_NT_LOADS=1 makes it a streaming (nontemporal)
+// load; plain loads are the default: the output kernel gathers 64-byte halves of 128-byte lines
+// whose other halves are gathered by a neighbouring CU of the same XCD, and a plain load keeps
+// the line in that XCD's L2 for it (27.4 vs 28.5 us per map, FETCH_SIZE back to the algorithmic
+// bytes once the gather is issued in two halves).
 #ifndef FC_NT_LOADS
-#define FC_NT_LOADS 1
+#define FC_NT_LOADS 0
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && FC_NT_LOADS
 #define FC_STREAM_LOAD16(dst, ptr)                                                         \
