@@ -36,7 +36,8 @@
 #define FC_COLS_STAMP(slot) ((void)0)
 #endif
 #ifndef FC_COLS_SPLIT_GATHER
-#define FC_COLS_SPLIT_GATHER 1   // 0: A/B, the whole gather of the next tile issued at the start of the tile
+#define FC_COLS_SPLIT_GATHER 2   // next tile's gather issued in: 0 one go at the start of the tile (A/B), 1 halves (start, after
+                                 // stage 3), 2 thirds (start, after stage 3, between the two rounds of stage 2): 28.3 / 27.4 / 27.2 us
 #endif
 #ifndef FC_COLS_NO_PREWAIT
 #define FC_COLS_NO_PREWAIT 0   // 1: A/B, without the vmcnt(0) ahead of the store burst
@@ -162,8 +163,10 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         if constexpr (PLAND) {   // rows 2p, 2p+1 = bins (p, M-p); one thread takes both for two columns
             const int tw = 1 << g.y_tile_shift;
             const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 >> g.y_tile_shift) * g.y_tile_elems + (w0 & (tw - 1));
-            constexpr int RH = (State::RNDU + 1) / 2;
-            constexpr int RB = (part == 2) ? RH : 0, RE = (part == 1) ? RH : State::RNDU;
+            // parts: FC_COLS_SPLIT_GATHER == 1: halves (1, 2); == 2: thirds (1, 2, 3)
+            constexpr int NP = (FC_COLS_SPLIT_GATHER == 2) ? 3 : 2;
+            constexpr int RB = (part == 0) ? 0 : (State::RNDU * (part - 1) + NP - 1) / NP;
+            constexpr int RE = (part == 0) ? State::RNDU : (part == NP ? State::RNDU : (State::RNDU * part + NP - 1) / NP);
             static_for<RB, RE>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int e = t + NT * r;
@@ -350,9 +353,12 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             if (next < g.ntiles) issue_gather(t, st, next, IC<2>{});
         });
         // C3: inverse stage 2 (radix R2, sub-length R3)
-        ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
+        ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, [[maybe_unused]] State& st) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
+                if constexpr (PLAND && FC_COLS_SPLIT_GATHER == 2 && r == 1) {   // last third of the gather between the two rounds
+                    if (next < g.ntiles) issue_gather(t, st, next, IC<3>{});
+                }
                 const int idx = t + NT * r;
                 if (idx < C::NB2 * T) {
                     const int col = idx / C::NB2, u = idx % C::NB2;
