@@ -70,10 +70,31 @@ def cpu_baseline(cfg, sample_filters):
     orc.conv_fft(img, kh, kw, ks, threads=0)
     dt = time.perf_counter() - t0
     P = ceil16(H + kh - 1) * ceil16(W + kw - 1)
-    return {"value": n * P / dt / 1e9, "unit": "Gpixel-filters/s", "cores": min(cores, n),
-            "kind": "port",
-            "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters), %.1f s wall"
-                      % (cfg, n, dt)}
+    res = {"value": n * P / dt / 1e9, "unit": "Gpixel-filters/s", "cores": min(cores, n),
+           "kind": "port",
+           "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters), %.1f s wall"
+                     % (cfg, n, dt)}
+    # sanity number beside the port: the same maths on a production CPU FFT -- SciPy's
+    # pocketfft, float32 rfft2 / irfft2, all host cores -- the closest stand-in for MATLAB's
+    # multithreaded fft2 / ifft2 on this host (image spectrum computed once, as the GPU path does)
+    try:
+        import numpy as np
+        import scipy.fft as sfft
+        workers = os.cpu_count() or 1
+        fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+        t0 = time.perf_counter()
+        D = sfft.rfft2(img, s=(fh, fw), axes=(0, 1), workers=workers)
+        m = min(n, 4)
+        for k in ks[:m]:
+            K = sfft.rfft2(k, s=(fh, fw), axes=(0, 1), workers=workers)
+            out = sfft.irfft2(D * K, s=(fh, fw), axes=(0, 1), workers=workers).sum(axis=2)
+        dt2 = time.perf_counter() - t0
+        res["scipy_pocketfft_f32"] = {"value": m * P / dt2 / 1e9, "unit": "Gpixel-filters/s", "cores": workers,
+                                      "sample": "%d filters, %.1f s wall" % (m, dt2)}
+        del D, K, out
+    except Exception as e:   # the sanity number is optional
+        res["scipy_pocketfft_f32"] = {"error": str(e)}
+    return res
 
 
 def main():
