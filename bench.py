@@ -39,6 +39,7 @@ CONFIGS = {
     "hd720": (720, 1280, 1, 31, 31, 128, 8),
     "mid2900": (2900, 2900, 1, 63, 63, 64, 9),
     "big8192": (8192, 8192, 1, 127, 127, 32, 10),   # 8448 x 8448 transforms
+    "big6000": (6000, 6000, 1, 63, 63, 32, 11),     # 6144 x 6144 transforms
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 

@@ -356,7 +356,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, [[maybe_unused]] State& st) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                if constexpr (PLAND && FC_COLS_SPLIT_GATHER == 2 && r == 1) {   // last third of the gather between the two rounds
+                if constexpr (PLAND && FC_COLS_SPLIT_GATHER == 2 && r == C::RND2 - 1) {   // last third of the gather: ahead of the last round
                     if (next < g.ntiles) issue_gather(t, st, next, IC<3>{});
                 }
                 const int idx = t + NT * r;

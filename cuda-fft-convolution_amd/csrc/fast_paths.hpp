@@ -23,6 +23,7 @@ namespace fc {
 //   2112 = 8 x 12 x 22, 2 rows (cfg5):                            528 / 352 / 192
 //   1152 = 6 x  8 x 24, 4 rows (cfg2's 1088 window):              768 / 576 / 192
 //   8448 = 16 x 24 x 22, 384 threads, two workgroups per CU (8192-sized images): 528 / 352 / 384
+//   6144 = 16 x 24 x 16, 384 threads, two workgroups per CU (images between 4224 and 6144): 384 / 256 / 384
 //   3072 = 8 x 24 x 16 (images around 2500 - 3000):               384 / 128 / 192
 //   1536 = 8 x 12 x 16, 2 rows (1280-wide images):                384 / 256 / 192
 //    768 = 4 x 12 x 16, 4 rows (640 / 720-sized images):          768 / 256 / 192
@@ -33,6 +34,9 @@ namespace fc {
     X(8448, 16, 24, 22, 384, 1, 3)  \
     X(8448, 16, 24, 22, 384, 1, 6)  \
     X(8448, 16, 24, 22, 384, 1, 24) \
+    X(6144, 16, 24, 16, 384, 1, 3)  \
+    X(6144, 16, 24, 16, 384, 1, 6)  \
+    X(6144, 16, 24, 16, 384, 1, 24) \
     X(4224, 8, 24, 22, 192, 1, 3)   \
     X(4224, 8, 24, 22, 192, 1, 6)   \
     X(4224, 8, 24, 22, 192, 1, 24)  \
@@ -141,6 +145,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   M = 1056 (FFT_H 2112, cfg5): 6 x 8 x 22, 16 columns per tile (full 128-byte lines), 768 threads
 //   M =  576 (transform 1152, cfg2): 6 x 8 x 12, 16 columns, 768 threads
 //   M = 4224 (transform 8448, 8192-sized images): 8 x 24 x 22, 4 columns per tile (LDS), 768 threads
+//   M = 3072 (transform 6144): 8 x 24 x 16, 4 columns per tile, 768 threads
 //   M = 1536 / 768 / 384 (transforms 3072 / 1536 / 768): 8 x 12 x 16 (8 columns), 6 x 8 x 16, 4 x 6 x 16
 //   M =  288 (transform 576, 512-sized images): 4 x 6 x 12, 16 columns, 384 threads
 //   M =  144 (FFT_H 288, cfg1): 4 x 6 x 6, 16 columns, 384 threads
@@ -148,6 +153,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   (32-byte gather pieces: 47.8 vs 36.1 us per map); kept for A/B via FFTCONV_COLS_T=4.
 #define FC_FAST_COL_CONFIGS(X)   \
     X(4224, 8, 24, 22, 4, 768)   \
+    X(3072, 8, 24, 16, 4, 768)   \
     X(2112, 8, 12, 22, 8, 768)   \
     X(2112, 8, 12, 22, 4, 384)   \
     X(1536, 8, 12, 16, 8, 768)   \

@@ -24,7 +24,11 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 (512, 512, 1, 31, 31, 2), (540, 500, 2, 37, 40, 1),    # 576 x 576 transforms
                 (720, 640, 1, 21, 31, 2), (1280, 720, 1, 63, 47, 1), (1400, 1500, 2, 9, 11, 1),   # 768 / 1536
                 (3000, 200, 1, 65, 31, 1), (150, 2900, 1, 7, 150, 1),   # 3072 in one dimension each
-                (20, 8192, 1, 5, 127, 1), (8192, 40, 1, 127, 9, 1)]     # 8448 in one dimension each (two workgroups per CU / 4-column tiles)
+                (20, 8192, 1, 5, 127, 1), (8192, 40, 1, 127, 9, 1),     # 8448 in one dimension each (two workgroups per CU / 4-column tiles)
+                (24, 6000, 1, 3, 100, 1), (6000, 40, 2, 90, 9, 1),      # 6144 in one dimension each
+                # both kernels specialised with the 4-column output tiles (M = 3072 / 4224) and a short
+                # row transform: the pair-adjacent intermediate + merge-while-landing path of those tiles
+                (6000, 250, 1, 60, 31, 2), (8192, 260, 1, 127, 20, 1)]
 VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent, pair_rows, cols_wide, fast_fwd)
     (0, 16, 0, 0, 1, 0, 1), (1, 16, 0, 0, 1, 0, 1), (1, 16, 0, 1, 1, 0, 0), (2, 16, 0, 0, 1, 0, 1), (2, 16, 0, 0, 1, 0, 0),
     (2, 16, 0, 0, 0, 0, 1), (2, 8, 0, 0, 1, 0, 1), (2, 8, 1, 0, 0, 0, 0), (2, 8, 2, 1, 0, 0, 1), (2, 16, 2, 1, 0, 0, 0),

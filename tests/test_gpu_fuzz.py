@@ -9,7 +9,7 @@ import util
 
 pytestmark = pytest.mark.gpu
 
-FAST_LENGTHS = [288, 576, 768, 1152, 1536, 2112, 3072, 4224, 8448]
+FAST_LENGTHS = [288, 576, 768, 1152, 1536, 2112, 3072, 4224, 6144, 8448]
 
 
 def _cases():
