@@ -238,3 +238,33 @@ def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle, monkeypa
     ref = oracle.conv_fft(data, kh, kw, [ks[i] for i in idx])
     for i, r in zip(idx, ref):
         assert util.rel_err(got[i], r) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,k", [(6000, 63), (8192, 127)])
+def test_gpu_big_square_walk_with_remainder(fftconv, monkeypatch, size, k):
+    """both dimensions on the 6144 / 8448 configurations (two row workgroups per CU, 4-column output
+    tiles, cropped window at 6000), 17 kernels = one full walk of 16 + a remainder of 1.  The float64
+    oracle needs minutes at this size, so the specialised path is compared with the generic kernels
+    (path mode 0, themselves pinned to the oracle at every smaller size) on the same inputs."""
+    torch = pytest.importorskip("torch")
+    H = W = size
+    n = 17
+    rng = np.random.default_rng(size)
+    data = rng.random((H, W, 1), dtype=np.float32)
+    ks = [rng.random((k, k, 1), dtype=np.float32) for _ in range(n)]
+    kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(x, (2, 1, 0)) for x in ks]))).cuda()
+    maps = {}
+    for mode in (2, 0):
+        set_variant(monkeypatch, (mode, 16, 0, 0))
+        with fftconv.Plan(H, W, 1, k, k) as p:
+            if mode == 2:
+                assert p.info.transform_h == p.info.transform_w and p.info.transform_h in (6144, 8448)
+            p.set_image(data)
+            od = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device="cuda")
+            p.convolve_packed_device(n, kd.data_ptr(), k, k, od.data_ptr())
+            p.synchronize()
+            maps[mode] = [od[j].cpu().numpy() for j in (0, 7, n - 1)]
+            del od
+    for a, b in zip(maps[2], maps[0]):
+        assert util.rel_err(a, b) < 1e-5
