@@ -268,3 +268,34 @@ def test_gpu_big_square_walk_with_remainder(fftconv, monkeypatch, size, k):
             del od
     for a, b in zip(maps[2], maps[0]):
         assert util.rel_err(a, b) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lh,lw", [(288, 288), (576, 768), (768, 576), (1152, 1536), (1536, 1152), (2112, 3072), (3072, 2112),
+                                   (4224, 576), (768, 4224), (6144, 288), (288, 6144), (8448, 768), (1536, 8448), (2112, 2112)])
+def test_gpu_every_fast_length_pair_vs_generic(fftconv, monkeypatch, lh, lw):
+    """both kernels specialised, every transform length at least once along h and along w, 17
+    kernels (multi-map walk + remainder), odd data sizes: specialised path (mode 2) against the
+    generic kernels (mode 0) on the same inputs"""
+    torch = pytest.importorskip("torch")
+    kh, kw = 9 + lh // 64, 7 + lw // 96
+    H, W = lh - kh + 1 - 3, lw - kw + 1 - 5
+    n = 17
+    rng = np.random.default_rng(lh * 10007 + lw)
+    data = rng.standard_normal((H, W, 1)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, 1)).astype(np.float32) for _ in range(n)]
+    kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(x, (2, 1, 0)) for x in ks]))).cuda()
+    maps = {}
+    for mode in (2, 0):
+        set_variant(monkeypatch, (mode, 16, 0, 0))
+        with fftconv.Plan(H, W, 1, kh, kw) as p:
+            if mode == 2:
+                assert (p.info.transform_h, p.info.transform_w) == (lh, lw)
+            p.set_image(data)
+            od = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device="cuda")
+            p.convolve_packed_device(n, kd.data_ptr(), kh, kw, od.data_ptr())
+            p.synchronize()
+            maps[mode] = od.cpu().numpy()
+            del od
+    for j in range(n):
+        assert util.rel_err(maps[2][j], maps[0][j]) < 1e-5
