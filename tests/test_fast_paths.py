@@ -206,7 +206,9 @@ def test_gpu_fast_kernels_many_maps_multi_feature(fftconv, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("group", [2, 5, -1])
 @pytest.mark.parametrize("shape", [(40, 4096, 1, 7, 127, 7), (2048, 300, 1, 63, 20, 7), (1024, 1024, 1, 63, 63, 7),
-                                   (256, 256, 1, 31, 31, 7), (300, 4096, 1, 20, 63, 11)])
+                                   (256, 256, 1, 31, 31, 7), (300, 4096, 1, 20, 63, 11),
+                                   (512, 512, 1, 31, 31, 7), (720, 640, 1, 21, 31, 7), (1280, 720, 1, 63, 47, 7),
+                                   (200, 3000, 1, 31, 65, 7), (150, 6000, 1, 9, 70, 7), (120, 8192, 1, 7, 127, 7)])
 def test_gpu_multi_map_row_kernel(fftconv, oracle, monkeypatch, shape, group):
     """several maps per workgroup with DISTINCT kernels (walk indexing, prefetch of the next kernel
     row, partial last walk: 7 = 2+2+2+1 = 5+2) on every fast row configuration"""
