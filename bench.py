@@ -5,20 +5,28 @@ A "step" is one pass of the hot path over one batch of synthetic input: the imag
 resident in HBM) is zero-padded and transformed once, then every filter of the batch is
 convolved with it, all maps staying device-resident (SURVEY.md 8(d) "timed region").
 
-Workload at N = 1 (default): BASELINE.json configs[2], the configuration the metric is quoted
-on -- 4096x4096 fp32 image, 256 kernels of 127x127, F = 1 -> 256 maps of 4224x4224.
-N > 1: the filters are sharded over the ranks (one process per GPU): every rank owns
-`--filters` kernels of the same image; rank 0 transforms the image and its spectrum is
-broadcast once over RCCL (torch.distributed "nccl"), the only collective on the path.  Per-GPU
-work is fixed, so "scaling" is "weak"; value is the whole-job rate (all ranks' maps / max time).
+N = 1 (default): BASELINE.json configs[2], the configuration the metric is quoted on --
+4096x4096 fp32 image, 256 kernels of 127x127, F = 1 -> 256 maps of 4224x4224.
+N > 1 (default): BASELINE.json configs[3] -- 4096x4096 image, 1024 kernels of 63x63 in total,
+sharded over the ranks in contiguous blocks (one process per GPU); rank 0 transforms the image and
+its spectrum is broadcast once per step over RCCL (torch.distributed "nccl"), the only
+collective on the path.  Total work is fixed, so "scaling" is "strong"; value is the whole-job
+rate (all maps / max time over ranks).  `--gpus N` run by hand starts the N ranks itself; under
+torch.distributed.run the ranks come from the environment.
+`--images n` is BASELINE configs[4]: n images (2048x2048 with --config cfg5) dealt over the ranks,
+every image against all kernels, H2D of the next image behind the compute of the current one.
+
+The steps themselves live in cuda-fft-convolution_amd/multi_gpu.py (shared with the tests).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
-kernel, algorithmic bytes / live HIP-event time) and `cpu_baseline` (the CPU oracle timed on
-this host on a bounded sample, rank 0 at N = 1 only).
+kernel, algorithmic bytes / live HIP-event time), `cpu_baseline` (the CPU oracle timed on this
+host on a bounded sample, rank 0 at N = 1 only) and `check_max_rel_err` (every map's checksum on
+the device + the oracle's maps where they were computed); a failed check exits non-zero.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,12 +35,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CONFIGS = {
-    # name: (H, W, F, kh, kw, filters per GPU, seed)
+    # name: (H, W, F, kh, kw, filters in total, seed)
     "cfg1": (256, 256, 1, 31, 31, 1, 1),
     "cfg2": (1024, 1024, 1, 63, 63, 16, 2),
     "cfg3": (4096, 4096, 1, 127, 127, 256, 3),
-    "cfg4": (4096, 4096, 1, 63, 63, 128, 4),   # 1024 kernels over 8 GPUs
-    "cfg5": (2048, 2048, 1, 63, 63, 64, 5),
+    "cfg4": (4096, 4096, 1, 63, 63, 1024, 4),   # over 8 GPUs: 128 each
+    "cfg5": (2048, 2048, 1, 63, 63, 64, 5),     # per image; 32 images over 8 GPUs (--images)
     # not a BASELINE config: the multi-feature form of the reference's demo (F planes summed per map)
     "cfg3f4": (4096, 4096, 4, 127, 127, 64, 6),
     "mid512": (512, 512, 1, 31, 31, 256, 7),   # not BASELINE configs: mid-sized images on the 576 / 768 / 1536 / 3072 transforms
@@ -42,6 +50,8 @@ CONFIGS = {
     "big6000": (6000, 6000, 1, 63, 63, 32, 11),     # 6144 x 6144 transforms
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+CHECK_TOL_ORACLE = 1e-4   # north_star parity bar (max|out - ref| / max|ref| per map)
+CHECK_TOL_CHECKSUM = 1e-5  # sum(map) vs sum(image) * sum(kernel), relative
 
 
 def ceil16(n):
@@ -58,44 +68,83 @@ def alg_bytes(H, W, F, kh, kw):
     return {"spectral_rows": spectral, "cols_c2r": out_cols, "total": spectral + out_cols, "P": P}
 
 
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(cfg, sample_filters):
     """Times the CPU oracle (port of demoCudaConvolutionFFT.m:78-102, complex128 full transforms)
-    on this host on a bounded sample of the same workload."""
+    on this host on a bounded sample of the same workload, plus two numbers beside it: the fp32
+    half-spectrum C++ restatement (oracle/fftconv_cpu_f32.cpp) and SciPy's pocketfft.
+    Returns (json object, oracle maps of the first filters for the self-check)."""
     import util
     H, W, F, kh, kw, _, seed = CONFIGS[cfg]
     orc = util.Oracle()
-    cores = orc.num_threads(0)
-    n = max(1, min(sample_filters, cores))
+    avail = host_cores()
+    total = os.cpu_count() or avail
+    threads = max(1, min(sample_filters, avail))
+    n = threads
     img, ks = util.synth(seed, H, W, F, kh, kw, n)
     t0 = time.perf_counter()
-    orc.conv_fft(img, kh, kw, ks, threads=0)
+    ref = orc.conv_fft(img, kh, kw, ks, threads=threads)
     dt = time.perf_counter() - t0
     P = ceil16(H + kh - 1) * ceil16(W + kw - 1)
-    res = {"value": n * P / dt / 1e9, "unit": "Gpixel-filters/s", "cores": min(cores, n),
+    res = {"value": n * P / dt / 1e9, "unit": "Gpixel-filters/s", "cores": threads,
            "kind": "port",
-           "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters), %.1f s wall"
-                     % (cfg, n, dt)}
-    # sanity number beside the port (SURVEY 8(d)): the same maths on a production CPU FFT -- SciPy's
-    # pocketfft, float32 rfft2 / irfft2, all host cores -- the closest stand-in for MATLAB's
-    # multithreaded fft2 / ifft2 on this host (image spectrum computed once, as the GPU path does)
+           "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters: %d of the host's %d "
+                     "cores, %d usable by this process), %.1f s wall" % (cfg, n, threads, total, avail, dt)}
+    # beside the port (SURVEY 8(d)): the same maths in fp32 with half spectra, C++ / OpenMP over filters
     try:
-        import numpy as np
-        import scipy.fft as sfft
-        workers = os.cpu_count() or 1
-        fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+        c32 = util.CpuF32()
         t0 = time.perf_counter()
-        D = sfft.rfft2(img, s=(fh, fw), axes=(0, 1), workers=workers)
+        c32.conv_fft(img, kh, kw, ks, threads=threads)
+        dt1 = time.perf_counter() - t0
+        res["f32_rfft2_port"] = {"value": n * P / dt1 / 1e9, "unit": "Gpixel-filters/s", "cores": threads,
+                                 "sample": "same image + %d filters, fp32 rfft2/irfft2 restatement, %.1f s wall" % (n, dt1)}
+    except Exception as e:   # optional
+        res["f32_rfft2_port"] = {"error": str(e)}
+    # ... and on a production CPU FFT: SciPy's pocketfft, float32 rfft2 / irfft2, every usable core --
+    # the closest stand-in for MATLAB's multithreaded fft2 / ifft2 on this host (image spectrum once)
+    try:
+        import scipy.fft as sfft
+        fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+        D = sfft.rfft2(img, s=(fh, fw), axes=(0, 1), workers=avail)   # untimed warm-up of the plan cache
+        t0 = time.perf_counter()
+        D = sfft.rfft2(img, s=(fh, fw), axes=(0, 1), workers=avail)
         m = min(n, 4)
         for k in ks[:m]:
-            K = sfft.rfft2(k, s=(fh, fw), axes=(0, 1), workers=workers)
-            out = sfft.irfft2(D * K, s=(fh, fw), axes=(0, 1), workers=workers).sum(axis=2)
+            K = sfft.rfft2(k, s=(fh, fw), axes=(0, 1), workers=avail)
+            out = sfft.irfft2(D * K, s=(fh, fw), axes=(0, 1), workers=avail).sum(axis=2)
         dt2 = time.perf_counter() - t0
-        res["scipy_pocketfft_f32"] = {"value": m * P / dt2 / 1e9, "unit": "Gpixel-filters/s", "cores": workers,
-                                      "sample": "%d filters, %.1f s wall" % (m, dt2)}
+        res["scipy_pocketfft_f32"] = {"value": m * P / dt2 / 1e9, "unit": "Gpixel-filters/s", "cores": avail,
+                                      "sample": "%d filters one after the other, %.1f s wall" % (m, dt2)}
         del D, K, out
-    except Exception as e:   # the sanity number is optional
+    except Exception as e:   # optional
         res["scipy_pocketfft_f32"] = {"error": str(e)}
-    return res
+    return res, ref
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` by hand: start the N ranks (fresh processes, before anything in
+    this one touches the GPU) and exit with their status; rank 0 prints the JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def main():
@@ -103,25 +152,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--filters", type=int, default=0, help="filters per GPU (0 = the config's)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: cfg3 on one GPU (BASELINE configs[2]), cfg4 on several (configs[3])")
+    ap.add_argument("--filters", type=int, default=0, help="filters of the whole job (0 = the config's); sharded over the ranks")
+    ap.add_argument("--weak", action="store_true", help="--filters (or the config's count) is per GPU: weak scaling")
     ap.add_argument("--batch-maps", type=int, default=0)
+    ap.add_argument("--rows-group", type=int, default=0, help="maps per workgroup of the spectral-row kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
-    ap.add_argument("--check", action="store_true", help="verify a few maps against the oracle after timing")
+    ap.add_argument("--check", action="store_true",
+                    help="also verify three maps of every rank against the oracle (the cheap all-maps checksum always runs)")
     ap.add_argument("--images", type=int, default=0,
-                    help="streamed mode (BASELINE configs[4]): each rank convolves this many images per step, every "
-                         "image with its own kernels' maps, the next image's H2D copy (pinned host memory, side "
+                    help="streamed mode (BASELINE configs[4]): this many images in total, dealt over the ranks; per rank "
+                         "every image against all kernels, the next image's H2D copy (pinned host memory, side "
                          "stream) overlapped with the current image's compute; no collective")
     ap.add_argument("--graph", action="store_true",
                     help="record one step into a HIP graph (plan bound to the capturing stream) and time graph "
                          "replays: removes the per-launch host cost that bounds the small configurations; "
                          "single-GPU, non-streamed steps only")
-    ap.add_argument("--no-overlap", action="store_true", help="blocking broadcast, no kernel-column overlap (A/B)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one spectrum buffer: image transform + broadcast of a step not overlapped with the previous step's maps (A/B)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import util
@@ -129,9 +187,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
@@ -143,16 +200,27 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     fc = util.load_package()
-    H, W, F, kh, kw, nf, seed = CONFIGS[args.config]
+    import importlib
+    mg = importlib.import_module(fc.__name__ + ".multi_gpu")
+    cfg = args.config or ("cfg4" if world > 1 else "cfg3")
+    H, W, F, kh, kw, nf_total, seed = CONFIGS[cfg]
     if args.filters > 0:
-        nf = args.filters
+        nf_total = args.filters
+    if args.weak:
+        nf_total *= world
+    streamed = args.images > 0
+    if streamed:          # image-sharded: every rank holds all the kernels
+        first, nf = 0, nf_total
+        img_first, n_img = mg.image_shard(args.images, rank, world)
+    else:                 # filter-sharded: contiguous blocks
+        first, nf = mg.filter_shard(nf_total, rank, world)
     img_h, _ = util.synth(seed, H, W, F, kh, kw, 0)
-    # kernels: seed 5678+cfg+k with k the GLOBAL filter index (rank-sharded contiguous blocks)
-    import numpy as np
-    kern_h = np.empty((nf, F, kw, kh), dtype=np.float32)  # [n][f][kw][kh] == n MATLAB arrays kh x kw x F
+    # kernels: seed 5678 + cfg + k with k the GLOBAL filter index
+    kern_h = np.empty((max(nf, 1), F, kw, kh), dtype=np.float32)  # [n][f][kw][kh] == n MATLAB arrays kh x kw x F
     for j in range(nf):
-        k = np.random.default_rng(5678 + seed + rank * nf + j).random((kh, kw, F), dtype=np.float32)
+        k = np.random.default_rng(5678 + seed + first + j).random((kh, kw, F), dtype=np.float32)
         kern_h[j] = np.transpose(k, (2, 1, 0))
+    kern_h = kern_h[:nf]
     img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(img_h, (2, 1, 0)))).to(dev)  # [f][w][h]
     kern_d = torch.from_numpy(kern_h).to(dev)
 
@@ -160,60 +228,33 @@ def main():
     plan = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream)
     info = plan.info
     P = info.fft_h * info.fft_w
-    spec = torch.empty(info.spectrum_bytes, dtype=torch.uint8, device=dev)
-    plan.use_spectrum_buffer(spec.data_ptr(), spec.numel())
-    out = torch.empty((nf, info.fft_w, info.fft_h), dtype=torch.float32, device=dev)
     if args.batch_maps:
         plan.set_option("batch_maps", args.batch_maps)
+    if args.rows_group:
+        plan.set_option("rows_group", args.rows_group)
+    # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
+    # the next image's H2D copy (streamed mode)
+    overlap = streamed or (use_dist and not args.no_overlap)
+    engine = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap)
+    out = engine.out
 
-    streamed = args.images > 0
     if streamed:
-        # images of this rank in pinned host memory (seeded per global image index), two device
-        # buffers, a side stream for the copies
-        n_img = args.images
+        # images of this rank in pinned host memory (seeded per global image index)
         imgs_h = []
         for i in range(n_img):
-            a = np.random.default_rng(1234 + seed + 1000 * (rank * n_img + i)).random((F, W, H), dtype=np.float32)
+            a = np.random.default_rng(1234 + seed + 1000 * (img_first + i)).random((F, W, H), dtype=np.float32)
             imgs_h.append(torch.from_numpy(a).pin_memory())
-        img_buf = [torch.empty((F, W, H), dtype=torch.float32, device=dev) for _ in range(2)]
-        copy_stream = torch.cuda.Stream(dev)
-        copied = [torch.cuda.Event() for _ in range(2)]
-        consumed = [torch.cuda.Event() for _ in range(2)]
+        conv = mg.ImageStreamedConvolver(engine, nf)
 
-    def step_streamed():
-        main = torch.cuda.current_stream(dev)
-        with torch.cuda.stream(copy_stream):
-            img_buf[0].copy_(imgs_h[0], non_blocking=True)
-            copied[0].record(copy_stream)
-        for i in range(n_img):
-            b = i & 1
-            if i + 1 < n_img:            # next image's H2D while this one is convolved
-                with torch.cuda.stream(copy_stream):
-                    if i >= 1:
-                        copy_stream.wait_event(consumed[1 - b])   # its buffer was read by image i-1's FFT
-                    img_buf[1 - b].copy_(imgs_h[i + 1], non_blocking=True)
-                    copied[1 - b].record(copy_stream)
-            main.wait_event(copied[b])
-            plan.set_image_device(img_buf[b].data_ptr())
-            consumed[b].record(main)
-            plan.convolve_packed_device(nf, kern_d.data_ptr(), kh, kw, out.data_ptr())
+        def run_steps(k):
+            for _ in range(k):
+                conv.run(imgs_h)
+    else:
+        conv = mg.FilterShardedConvolver(engine, dist if use_dist else None, rank, world, nf_total, src=0,
+                                         depth=2 if overlap else 1, always_collective=args.force_collective)
 
-    def step():
-        if streamed:
-            return step_streamed()
-        if rank == 0:
-            plan.set_image_device(img_d.data_ptr())
-        if use_dist and not streamed:
-            # the kernels' column transforms do not need the image: they run while the spectrum
-            # travels (rank 0: after its image pass; the others: from the start of the step)
-            if args.no_overlap:
-                dist.broadcast(spec, src=0)
-            else:
-                work = dist.broadcast(spec, src=0, async_op=True)
-                plan.prepare_kernels_packed_device(nf, kern_d.data_ptr(), kh, kw)
-                work.wait()        # the plan's stream waits for the broadcast, the host does not
-        plan.mark_spectrum_valid()
-        plan.convolve_packed_device(nf, kern_d.data_ptr(), kh, kw, out.data_ptr())
+        def run_steps(k):
+            conv.run([img_d] * k)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -221,29 +262,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
-    run_step = step
     graph = None
     if args.graph:
         if use_dist or streamed:
             raise SystemExit("--graph: single-GPU, non-streamed steps only")
-        step()                                   # scratch buffers are sized: nothing allocates from here on
+        run_steps(1)                             # scratch buffers are sized: nothing allocates from here on
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         cap_stream = torch.cuda.Stream(dev)
         with torch.cuda.graph(graph, stream=cap_stream):
-            plan.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            step()
+            cur = torch.cuda.current_stream(dev)
+            plan.set_stream(cur.cuda_stream)
+            engine.main_stream = cur
+            run_steps(1)
         plan.set_stream(stream.cuda_stream)
-        run_step = graph.replay
+        engine.main_stream = stream
         for _ in range(max(1, args.warmup)):
-            run_step()
+            graph.replay()
         barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
+    if graph is not None:
+        for _ in range(args.steps):
+            graph.replay()
+    else:
+        run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -251,17 +295,55 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # self-check of what the timed steps left in `out` (every map of this rank, on the device):
+    # the sum over the whole window of a linear convolution is sum(image) * sum(kernel)
+    chk_img = img_d
+    if streamed and n_img:
+        chk_img = conv.buf[(n_img - 1) & 1]       # the maps in `out` belong to the last image of the step
+    check = {"checksum_max_rel_err": 0.0}
+    if nf and (not streamed or n_img):
+        s_img = chk_img.sum(dim=(1, 2), dtype=torch.float64)                        # [F]
+        s_ker = kern_d.sum(dim=(2, 3), dtype=torch.float64)                         # [n][F]
+        want = (s_ker * s_img[None, :]).sum(dim=1)
+        got = out[:nf].sum(dim=(1, 2), dtype=torch.float64)
+        check["checksum_max_rel_err"] = float(((got - want).abs() / want.abs().clamp_min(1e-30)).max().item())
+    chk_img_h = None
+    if args.check:
+        chk_img_h = np.asfortranarray(np.transpose(chk_img.cpu().numpy(), (2, 1, 0)))
+
     # per-kernel HIP-event timing of the same steps, on the plan's stream (separate pass so the
     # event records do not sit inside the headline timing)
     plan.set_option("profile", 1)
     plan.profile(reset=True)
-    for _ in range(max(1, min(args.steps, 3))):
-        step()
+    run_steps(max(1, min(args.steps, 3)))
     torch.cuda.synchronize(dev)
     prof = plan.profile(reset=True)
     plan.set_option("profile", 0)
 
     result = None
+    errs = []
+    if args.check and nf:       # three maps of every rank against the oracle
+        orc = util.Oracle()
+        idx = sorted(set([0, nf // 2, nf - 1]))
+        ks = [np.asfortranarray(np.transpose(kern_h[j], (2, 1, 0))) for j in idx]
+        ref = orc.conv_fft(chk_img_h, kh, kw, ks)
+        for j, r in zip(idx, ref):
+            errs.append(util.rel_err(out[j].cpu().numpy().T, r))   # [w][h] -> h x w
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, ref = cpu_baseline(cfg, args.cpu_sample)
+        if not streamed:        # the oracle's maps of the first filters double as a check
+            for j, r in enumerate(ref[:nf]):
+                errs.append(util.rel_err(out[j].cpu().numpy().T, r))
+    oracle_err = max(errs) if errs else None
+    if use_dist:
+        tt = torch.tensor([check["checksum_max_rel_err"], oracle_err if oracle_err is not None else -1.0],
+                          dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        check["checksum_max_rel_err"] = float(tt[0].item())
+        oracle_err = float(tt[1].item()) if tt[1].item() >= 0 else None
+    ok = check["checksum_max_rel_err"] < CHECK_TOL_CHECKSUM and (oracle_err is None or oracle_err < CHECK_TOL_ORACLE)
+
     if rank == 0:
         ab = alg_bytes(H, W, F, kh, kw)
         per = {}
@@ -274,15 +356,17 @@ def main():
                              "gbps": ab[name] * units / (avg_ms * 1e-3) / 1e9}
         dom = max(per, key=lambda k: prof[k]["ms"]) if per else None
         traffic = None
+        traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if dom and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                per_map = tj.get(args.config, {}).get(dom)
+                per_map = tj.get(cfg, {}).get(dom)
                 traffic = per_map * per[dom]["units_per_launch"] if per_map else None
+                traffic_src = tj.get("_source")
             except Exception:
                 traffic = None
-        total_maps = nf * world * (args.images if streamed else 1)
+        total_maps = (nf_total * args.images) if streamed else nf_total
         value = total_maps * P * args.steps / dt / 1e9
         result = {
             "metric": "Gpixel-filters/s (padded FFT size)",
@@ -293,44 +377,38 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if (args.weak or streamed) else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: %dx%d image (F=%d), %d kernels of %dx%d per GPU -> %d maps of %dx%d, %s"
-                                   % (args.config, H, W, F, nf, kh, kw, total_maps, info.fft_h, info.fft_w,
+            "config": {"workload": "%s: %dx%d image (F=%d), %d kernels of %dx%d in total%s -> %d maps of %dx%d per step, %s"
+                                   % (cfg, H, W, F, nf_total, kh, kw,
+                                      (" against each of %d images" % args.images) if streamed else "",
+                                      total_maps, info.fft_h, info.fft_w,
                                       "image-sharded" if streamed else "filter-sharded"),
                        "transform": [info.transform_h, info.transform_w],
-                       "filters_per_gpu": nf,
+                       "filters_total": nf_total,
+                       "filters_per_gpu": nf if streamed else -(-nf_total // world),
                        "hip_graph_replay": bool(args.graph),
-                       "images_per_gpu_per_step": args.images if streamed else 1,
+                       "images_per_step": args.images if streamed else 1,
                        "parallelism": ("images x%d, streamed H2D" % world) if streamed else
-                                      ("filters x%d + 1 bcast" % world if world > 1 else "single GPU")},
+                                      ("filters x%d + 1 bcast per step" % world if world > 1 else "single GPU")},
             "hbm_algorithmic_gbps": ab["total"] * total_maps * args.steps / dt / 1e9,
             "hbm_frac_of_peak": ab["total"] * total_maps * args.steps / dt / 1e9 / (HBM_PEAK_GBPS * world),
             "kernels": per,
             "image_ms": (prof["image_cols"]["ms"] + prof["image_rows"]["ms"]) / max(1, prof["image_cols"]["launches"]),
+            "check_max_rel_err": oracle_err,
+            "check_checksum_max_rel_err": check["checksum_max_rel_err"],
+            "check_ok": ok,
         }
         if dom:
             result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per[dom]["gbps"], "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s", "frac": per[dom]["gbps"] / HBM_PEAK_GBPS, "traffic": traffic,
+                                  "traffic_source": traffic_src,
                                   "algorithmic_bytes_per_launch": ab[dom] * per[dom]["units_per_launch"],
                                   "avg_launch_ms": per[dom]["avg_ms"]}
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample)
-        if args.check:
-            orc = util.Oracle()
-            idx = sorted(set([0, nf // 2, nf - 1]))
-            ks = [np.asfortranarray(np.transpose(kern_h[j], (2, 1, 0))) for j in idx]
-            img_chk = img_h
-            if streamed:   # the maps in `out` belong to the last image of the step
-                img_chk = np.asfortranarray(np.transpose(imgs_h[-1].numpy(), (2, 1, 0)))
-            ref = orc.conv_fft(img_chk, kh, kw, ks)
-            errs = []
-            for j, r in zip(idx, ref):
-                g = out[j].cpu().numpy().T  # [w][h] -> h x w
-                errs.append(util.rel_err(g, r))
-            result["check_max_rel_err"] = max(errs)
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -345,6 +423,10 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+    if not ok:
+        print("bench.py: self-check FAILED on rank %d (checksum %.3g, oracle %s)"
+              % (rank, check["checksum_max_rel_err"], oracle_err), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

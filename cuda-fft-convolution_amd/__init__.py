@@ -49,6 +49,24 @@ class PlanInfo(ctypes.Structure):
     ]
 
 
+class PlanOptions(ctypes.Structure):
+    """fftconv_plan_options (include/fftconv.h): choices fixed at plan creation."""
+    _fields_ = [("struct_size", ctypes.c_size_t), ("kernel_path", ctypes.c_int), ("rows_group", ctypes.c_int),
+                ("max_transform", ctypes.c_int)]
+
+    def __init__(self, kernel_path=0, rows_group=0, max_transform=0):
+        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform))
+
+
+def _options_ptr(options):
+    """None, a PlanOptions or a dict of its fields -> (pointer or None, keep-alive)"""
+    if options is None:
+        return None, None
+    if isinstance(options, dict):
+        options = PlanOptions(**options)
+    return ctypes.byref(options), options
+
+
 class Profile(ctypes.Structure):
     _fields_ = [("ms", ctypes.c_double * 5), ("launches", ctypes.c_long * 5), ("units", ctypes.c_long * 5)]
 
@@ -62,12 +80,15 @@ class Profile(ctypes.Structure):
 # every symbol include/fftconv.h declares
 EXPORTED_SYMBOLS = (
     "fftconv_fft_size16", "fftconv_last_error", "fftconv_version", "fftconv_device_count",
-    "fftconv_convolution_fft", "fftconv_plan_create", "fftconv_plan_destroy", "fftconv_plan_get_info",
+    "fftconv_convolution_fft", "fftconv_convolution_fft_ex", "fftconv_plan_create", "fftconv_plan_create_ex",
+    "fftconv_plan_is_live", "fftconv_plan_destroy", "fftconv_plan_get_info",
     "fftconv_plan_set_image", "fftconv_plan_spectrum", "fftconv_plan_mark_spectrum_valid",
     "fftconv_plan_use_spectrum_buffer",
     "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_prepare_kernels_packed",
     "fftconv_plan_synchronize", "fftconv_plan_set_stream",
     "fftconv_plan_set_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
+    "fftconv_multi_create", "fftconv_multi_destroy", "fftconv_multi_set_image", "fftconv_multi_convolve",
+    "fftconv_multi_shard", "fftconv_multi_size", "fftconv_multi_plan", "fftconv_convolution_fft_multi",
 )
 
 _lib = None
@@ -111,7 +132,10 @@ def load_library():
     lib.fftconv_version.restype = ctypes.c_char_p
     lib.fftconv_device_count.argtypes = [pi]
     lib.fftconv_convolution_fft.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, pi, pi]
+    lib.fftconv_convolution_fft_ex.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, pi, pi, vp]
     lib.fftconv_plan_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, vp]
+    lib.fftconv_plan_create_ex.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, vp, vp]
+    lib.fftconv_plan_is_live.argtypes = [vp]
     lib.fftconv_plan_destroy.argtypes = [vp]
     lib.fftconv_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
     lib.fftconv_plan_set_image.argtypes = [vp, vp, ci]
@@ -127,6 +151,14 @@ def load_library():
     lib.fftconv_plan_get_profile.argtypes = [vp, ctypes.POINTER(Profile), ci]
     lib.fftconv_fft_data.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
     lib.fftconv_conv_fft_data.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp]
+    lib.fftconv_multi_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, pi, ci, vp]
+    lib.fftconv_multi_destroy.argtypes = [vp]
+    lib.fftconv_multi_set_image.argtypes = [vp, vp, ci]
+    lib.fftconv_multi_convolve.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci]
+    lib.fftconv_multi_shard.argtypes = [vp, ci, ci, pi, pi]
+    lib.fftconv_multi_size.argtypes = [vp]
+    lib.fftconv_multi_plan.argtypes = [vp, ci, ctypes.POINTER(vp), pi]
+    lib.fftconv_convolution_fft_multi.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, pi, ci, vp, pi, pi]
     _lib = lib
     return lib
 
@@ -177,9 +209,10 @@ def _thread_size(threads):
     return ctypes.c_void_p(t.ctypes.data), int(t.size), t
 
 
-def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None, gpuId=0):
+def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None, gpuId=0, options=None):
     """One-shot convolution, host arrays in / host arrays out (list of FFT_H x FFT_W float32,
-    Fortran order).  Mirrors the MEX entry of src/cudaConvolutionFFT.cu."""
+    Fortran order).  Mirrors the MEX entry of src/cudaConvolutionFFT.cu.  ``options``: a
+    PlanOptions (or a dict of its fields) for fftconv_convolution_fft_ex."""
     lib = load_library()
     if not isinstance(kernelCell, (list, tuple)):
         raise FFTConvError(-1, "Kernel must be a cell array")  # src/cudaConvolutionFFT.cu:64-65
@@ -192,9 +225,10 @@ def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None
     optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
     tptr, tn, _keep = _thread_size(threadSize)
     ofh, ofw = ctypes.c_int(0), ctypes.c_int(0)
-    _check(lib.fftconv_convolution_fft(ctypes.c_void_p(d.ctypes.data), H, W, F, int(maxKernelH), int(maxKernelW),
-                                       n, kptr, kh, kw, kf, tptr, tn, int(gpuId), optr,
-                                       ctypes.byref(ofh), ctypes.byref(ofw)))
+    oref, _okeep = _options_ptr(options)
+    _check(lib.fftconv_convolution_fft_ex(ctypes.c_void_p(d.ctypes.data), H, W, F, int(maxKernelH), int(maxKernelW),
+                                          n, kptr, kh, kw, kf, tptr, tn, int(gpuId), optr,
+                                          ctypes.byref(ofh), ctypes.byref(ofw), oref))
     assert (ofh.value, ofw.value) == (fh, fw)
     return outs
 
@@ -203,11 +237,12 @@ class Plan:
     """Plan API: image spectrum computed once, reused for any number of kernels.  Pointers are
     plain integers (e.g. ``torch.Tensor.data_ptr()``); torch is not a dependency of this module."""
 
-    def __init__(self, H, W, F, maxKernelH, maxKernelW, gpuId=0, stream=0):
+    def __init__(self, H, W, F, maxKernelH, maxKernelW, gpuId=0, stream=0, options=None):
         self._lib = load_library()
         self._h = ctypes.c_void_p(None)
-        _check(self._lib.fftconv_plan_create(ctypes.byref(self._h), int(H), int(W), int(F), int(maxKernelH),
-                                             int(maxKernelW), int(gpuId), ctypes.c_void_p(int(stream) or None)))
+        oref, _okeep = _options_ptr(options)
+        _check(self._lib.fftconv_plan_create_ex(ctypes.byref(self._h), int(H), int(W), int(F), int(maxKernelH),
+                                                int(maxKernelW), int(gpuId), ctypes.c_void_p(int(stream) or None), oref))
         self.info = PlanInfo()
         _check(self._lib.fftconv_plan_get_info(self._h, ctypes.byref(self.info)))
 
@@ -295,6 +330,9 @@ class Plan:
     def synchronize(self):
         _check(self._lib.fftconv_plan_synchronize(self._h))
 
+    def is_live(self):
+        return bool(self._h is not None and self._h.value and self._lib.fftconv_plan_is_live(self._h))
+
     def set_stream(self, stream):
         """re-bind the plan to another HIP stream (integer handle, 0 = default stream)"""
         _check(self._lib.fftconv_plan_set_stream(self._h, ctypes.c_void_p(int(stream) or None)))
@@ -307,6 +345,88 @@ class Plan:
         pr = Profile()
         _check(self._lib.fftconv_plan_get_profile(self._h, ctypes.byref(pr), 1 if reset else 0))
         return pr.as_dict()
+
+
+def cudaConvolutionFFTMulti(data, maxKernelH, maxKernelW, kernelCell, gpuIds):
+    """One-shot convolution over several GPUs from this one process (fftconv_convolution_fft_multi:
+    what src/cudaConvFFTDataStreams.cu set out to be): image transformed on gpuIds[0], spectrum
+    peer-copied, kernels dealt in contiguous blocks.  Host arrays in / out like cudaConvolutionFFT."""
+    lib = load_library()
+    if not isinstance(kernelCell, (list, tuple)):
+        raise FFTConvError(-1, "Kernel must be a cell array")
+    d = _as_matlab_single(data, "data")
+    H, W, F = d.shape
+    ks, kptr, kh, kw, kf = _kernel_tables(kernelCell)
+    n = len(ks)
+    fh, fw = fft_size16(H + int(maxKernelH) - 1), fft_size16(W + int(maxKernelW) - 1)
+    outs = [np.empty((fh, fw), dtype=np.float32, order="F") for _ in range(n)]
+    optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    devs = (ctypes.c_int * len(gpuIds))(*[int(g) for g in gpuIds])
+    ofh, ofw = ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib.fftconv_convolution_fft_multi(ctypes.c_void_p(d.ctypes.data), H, W, F, int(maxKernelH), int(maxKernelW),
+                                             n, kptr, kh, kw, kf, devs, len(gpuIds), optr, ctypes.byref(ofh), ctypes.byref(ofw)))
+    return outs
+
+
+class MultiPlan:
+    """fftconv_multi_*: one plan per listed device driven from this process (image spectrum on
+    gpuIds[0], peer copies, contiguous kernel blocks)."""
+
+    def __init__(self, H, W, F, maxKernelH, maxKernelW, gpuIds, options=None):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p(None)
+        devs = (ctypes.c_int * len(gpuIds))(*[int(g) for g in gpuIds])
+        oref, _okeep = _options_ptr(options)
+        _check(self._lib.fftconv_multi_create(ctypes.byref(self._h), int(H), int(W), int(F), int(maxKernelH), int(maxKernelW),
+                                              devs, len(gpuIds), oref))
+        self.shape = (int(H), int(W), int(F))
+        p, dev = ctypes.c_void_p(None), ctypes.c_int(0)
+        _check(self._lib.fftconv_multi_plan(self._h, 0, ctypes.byref(p), ctypes.byref(dev)))
+        self.info = PlanInfo()
+        _check(self._lib.fftconv_plan_get_info(p, ctypes.byref(self.info)))
+
+    def __len__(self):
+        return self._lib.fftconv_multi_size(self._h)
+
+    def shard(self, n_kernel, index):
+        first, count = ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib.fftconv_multi_shard(self._h, int(n_kernel), int(index), ctypes.byref(first), ctypes.byref(count)))
+        return first.value, count.value
+
+    def set_image(self, data):
+        d = _as_matlab_single(data, "data")
+        if d.shape != self.shape:
+            raise FFTConvError(-1, "Invalid data input: shape %s does not match the plan" % (d.shape,))
+        _check(self._lib.fftconv_multi_set_image(self._h, ctypes.c_void_p(d.ctypes.data), HOST))
+
+    def convolve(self, kernelCell):
+        ks, kptr, kh, kw, kf = _kernel_tables(kernelCell)
+        for k in ks:
+            if k.shape[2] != self.shape[2]:
+                raise FFTConvError(-3, "Kernel and Data must have the same number of features and kernel "
+                                       "size should be smaller than data size")
+        n = len(ks)
+        outs = [np.empty((self.info.fft_h, self.info.fft_w), dtype=np.float32, order="F") for _ in range(n)]
+        optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        _check(self._lib.fftconv_multi_convolve(self._h, n, kptr, kh, kw, HOST, optr, HOST))
+        return outs
+
+    def destroy(self):
+        if self._h is not None and self._h.value:
+            self._lib.fftconv_multi_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def cudaFFTData(data, kernelH, kernelW, gpuId=0):

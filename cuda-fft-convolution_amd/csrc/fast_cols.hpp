@@ -87,14 +87,11 @@ struct FastColsArgs {
                              // every column < fft_w exists in Y
     int tiles_per_kernel;    // fft_w / T
     int ntiles;              // tiles_per_kernel * kernels in this launch
-    int y_tiled;             // 1: Y is tiled [w / TL][p][TL] in this kernel's LDS order (fast_rows.hpp)
-    int y_tile_elems;        // (M+1) * TL
-    int y_tile_shift;        // log2(TL), TL = 8 or 16 (tiled, not precombined)
-    int y_pair_rows;         // 1 (with y_tiled): rows of bins (k, M-k) adjacent, M+2 rows per tile (mode 3)
-    int y_precombined;       // 1: Y holds the merged rows Z (fast_rows_pair.hpp): M rows per 8-column tile,
-                             //    contiguous, tile row u lands at LDS position lpos[u]; no pair pass here
-    const int* lpos;         // LDS landing position of tile row u (precombined: M entries; tiled: M+1)
-    const int* rowoff;       // M+1 entries: Y row offset (row * y_pitch) feeding LDS position p
+    int y_tiled;             // 1: Y is tiled [w / TL][row][TL] with the rows of bins (k, M-k) adjacent (rows 2k, 2k+1;
+                             //    M+2 rows per tile): merged in registers on the way into LDS.  0: row-major [i][y_pitch]
+    int y_tile_elems;        // (M+2) * TL
+    int y_tile_shift;        // log2(TL): TL = 16, one 128-byte line per row and tile
+    const int* rowoff;       // row-major Y only, M+1 entries: Y row offset (row * y_pitch) feeding LDS position p
     const c32* tw1;          // w_M^j, j < m1
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
     const PairEntry* pairs;  // NPE entries: [0] DC/Nyquist, [k] pair (k, M-k), [M/2] middle (w = w_N^k)
@@ -108,7 +105,7 @@ struct ColState {
     int off[C::UPT];     // Y row offsets (or, precombined, LDS landing positions) of this thread's gather units
 };
 
-// MODE 3 (pair-adjacent rows, merge while landing): rows of bins k and M-k come as pairs
+// tiled intermediate (pair-adjacent rows, merge while landing): rows of bins k and M-k come as pairs
 template <class C>
 struct ColPairState {
     static constexpr int NPU = (C::M / 2 + 1) * (C::T / 2);        // pair units (pair, 2 columns) per tile
@@ -117,16 +114,15 @@ struct ColPairState {
     c32x2 pb[RNDU];      // row of bin M-k (or Nyquist / padding)
 };
 
-// MODE: layout of the intermediate -- 0 row-major [i][y_pitch], 1 tiled, 2 precombined + tiled,
-// 3 tiled with the rows of bins (k, M-k) adjacent: one thread gathers both rows of a pair for two
-// columns and merges them in registers on the way into LDS, so the separate table-driven pair
-// pass over LDS (and its barrier) disappears (see FastColsArgs).  A template parameter so that each variant carries only its own address
-// arithmetic (the kernel sits right at the 168-VGPR budget of 3 waves per SIMD).
-template <class C, int MODE, class Ctx>
+// TILED: layout of the intermediate -- false: row-major [i][y_pitch] (the producer is a generic
+// kernel), gathered through `rowoff` and merged by a table-driven pair pass over LDS; true: tiled
+// with the rows of bins (k, M-k) adjacent: one thread gathers both rows of a pair for two columns
+// and merges them in registers on the way into LDS, so the pair pass (and its barrier) disappears.
+// A template parameter so that each variant carries only its own address arithmetic (the kernel
+// sits right at the 168-VGPR budget of 3 waves per SIMD).
+template <class C, bool TILED, class Ctx>
 FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
-    constexpr bool PRE = (MODE == 2);
-    constexpr bool TILED = (MODE == 1);
-    constexpr bool PLAND = (MODE == 3);
+    constexpr bool PLAND = TILED;
     constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
     constexpr int T2 = T / 2;
     using State = std::conditional_t<PLAND, ColPairState<C>, ColState<C>>;
@@ -143,14 +139,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     // run of tiles.  Falls back to the plain order when nwg is not a multiple of 8.
     const int per_xcd = nwg / 8;
     const int wg_x = (nwg % 8 == 0) ? (wg % 8) * per_xcd + wg / 8 : wg;
-    // Tile sequence of this workgroup: it-th tile.  With the 16-column tiled layout (two kernel
-    // tiles per 128-byte line) a workgroup takes both halves of a layout tile back to back, so
-    // the second half is served by L2 / Infinity Cache instead of a second HBM fetch.
-    const bool halves = false;   // measured slower than running the two halves concurrently on one XCD
-    auto tile_of = [&](int it) -> int {
-        if (halves) return ((it >> 1) * nwg + wg_x) * 2 + (it & 1);
-        return it * nwg + wg_x;
-    };
+    auto tile_of = [&](int it) -> int { return it * nwg + wg_x; };   // it-th tile of this workgroup
     const int first_tile = tile_of(0);
 
     // part: 0 = the whole gather; 1 / 2 (mode 3) = its first / second half of rounds -- a CU cannot
@@ -178,25 +167,6 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     }
                 }
             });
-        } else if constexpr (PRE) {   // one contiguous block of M rows x T columns per tile
-            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 / T) * g.y_tile_elems;
-            static_for<0, C::UPT>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
-                const int e = t + NT * r;
-                if constexpr (!(FC_COLS_DBG & 4)) st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + 2 * e);
-            });
-        } else if constexpr (TILED) {   // rows of an 8- or 16-column layout tile
-            const int tw = 1 << g.y_tile_shift;   // layout tile width: a multiple of T
-            const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 >> g.y_tile_shift) * g.y_tile_elems + (w0 & (tw - 1));
-            static_for<0, C::UPT>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
-                const int e = t + NT * r;
-                if constexpr ((FC_COLS_DBG & 16) != 0)   // timing experiment: contiguous half-tile
-                    st.pre[r] = *reinterpret_cast<const c32x2*>(Yt - (w0 & (tw - 1)) + (size_t)((w0 & (tw - 1)) / T) * (M * T) + 2 * e);
-                else if constexpr (!(FC_COLS_DBG & 4))
-                    st.pre[r] = *reinterpret_cast<const c32x2*>(Yt + ((e / T2) << g.y_tile_shift) + 2 * (e % T2));
-            });
-            if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Yt + (M << g.y_tile_shift) + 2 * t);
         } else {
             const c32* Y = g.Y + (size_t)kernel * g.y_kernel_stride + w0;
             static_for<0, C::UPT>([&](auto r_) {
@@ -247,11 +217,11 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             constexpr int r = decltype(r_)::value;
             const int e = t + NT * r;
             const int t2 = e % T2;
-            const int p = (PRE || TILED) ? st.off[r] : e / T2;
+            const int p = e / T2;
             lds[(2 * t2) * LP + p] = st.pre[r].a;
             lds[(2 * t2 + 1) * LP + p] = st.pre[r].b;
         });
-        if (!PRE && t < T2) {
+        if (t < T2) {
             lds[(2 * t) * LP + M] = st.pre_ny.a;
             lds[(2 * t + 1) * LP + M] = st.pre_ny.b;
         }
@@ -262,8 +232,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     ctx.phase([&](int t, State& st) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
         for (int i = t; i < m1; i += NT) tw1[i] = g.tw1[i];
-        if constexpr (!PRE)
-            for (int i = t; i < C::NPE; i += NT) {
+        for (int i = t; i < C::NPE; i += NT) {
                 const PairEntry e = g.pairs[i];
                 ppos[i] = (unsigned)e.a | ((unsigned)e.b << 16);
                 if ((i & 31) == 0) wh[i >> 5] = e.w;      // w^(32*hi)
@@ -272,7 +241,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         if constexpr (!PLAND)
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            st.off[r] = (PRE || TILED) ? g.lpos[(t + NT * r) / T2] : g.rowoff[(t + NT * r) / T2];
+            st.off[r] = g.rowoff[(t + NT * r) / T2];
         });
         if (first_tile < g.ntiles) issue_gather(t, st, first_tile, IC<0>{});
     });
@@ -289,7 +258,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
 
         // C1: issue the next tile's gather (lands after C4), then merge the half spectrum of
         // this tile into the packed complex sequence, in place (table driven)
-        if constexpr (PRE || PLAND) ctx.phase_nosync([&](int t, State& st) {
+        if constexpr (PLAND) ctx.phase_nosync([&](int t, State& st) {
             if (next < g.ntiles) issue_gather(t, st, next, IC<(PLAND && FC_COLS_SPLIT_GATHER) ? 1 : 0>{});
         });
         else ctx.phase([&](int t, State& st) {

@@ -9,10 +9,8 @@
 
 #include "fast_cols.hpp"
 #include "fast_cols_fwd.hpp"
-#include "fast_cols_wide.hpp"
 #include "fast_rows.hpp"
 #include "fast_rows_multi.hpp"
-#include "fast_rows_pair.hpp"
 #include "planner.hpp"
 
 namespace fc {
@@ -79,7 +77,7 @@ inline FastRowsInfo fast_rows_lookup(int L, int max_kw) {
     return r;
 }
 
-inline bool fast_rows_length(int L) { return fast_rows_lookup(L, 1).ok; }
+inline bool fast_rows_length(int L, int max_kw) { return fast_rows_lookup(L, max_kw < 1 ? 1 : max_kw).ok; }
 
 // Calls run.template go<Cfg, NZ2>() for the first listed configuration of length L whose NZ2
 // covers `nz2_needed` (configurations are listed with ascending NZ2).  false if there is none.
@@ -89,21 +87,6 @@ inline bool fast_rows_dispatch(int L, int nz2_needed, Runner&& run) {
     if (L == LL && nz2_needed <= NZ) {                          \
         run.template go<RowCfg<LL, A, B, C, NTT, RP>, NZ>();    \
         return true;                                            \
-    }
-    FC_FAST_ROW_CONFIGS(FC_X)
-#undef FC_X
-    return false;
-}
-
-// Variants built on one-row-per-workgroup configurations only (paired rows, persistent).
-template <class Runner>
-inline bool fast_rows_rpw1_dispatch(int L, int nz2_needed, Runner&& run) {
-#define FC_X(LL, A, B, C, NTT, RP, NZ)                                      \
-    if constexpr (RP == 1) {                                                \
-        if (L == LL && nz2_needed <= NZ) {                                  \
-            run.template go<RowCfg<LL, A, B, C, NTT, RP>, NZ>();            \
-            return true;                                                    \
-        }                                                                   \
     }
     FC_FAST_ROW_CONFIGS(FC_X)
 #undef FC_X
@@ -149,13 +132,12 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   M = 1536 / 768 / 384 (transforms 3072 / 1536 / 768): 8 x 12 x 16 (8 columns), 6 x 8 x 16, 4 x 6 x 16
 //   M =  288 (transform 576, 512-sized images): 4 x 6 x 12, 16 columns, 384 threads
 //   M =  144 (FFT_H 288, cfg1): 4 x 6 x 6, 16 columns, 384 threads
-//   M = 2112 also as 4 columns / 384 threads (two workgroups per CU): measured much slower
-//   (32-byte gather pieces: 47.8 vs 36.1 us per map); kept for A/B via FFTCONV_COLS_T=4.
+//   (M = 2112 as 4 columns / 384 threads, two workgroups per CU, was measured much slower: 32-byte
+//   gather pieces, 47.8 vs 36.1 us per map)
 #define FC_FAST_COL_CONFIGS(X)   \
     X(4224, 8, 24, 22, 4, 768)   \
     X(3072, 8, 24, 16, 4, 768)   \
     X(2112, 8, 12, 22, 8, 768)   \
-    X(2112, 8, 12, 22, 4, 384)   \
     X(1536, 8, 12, 16, 8, 768)   \
     X(1056, 6, 8, 22, 16, 768)   \
     X(768, 6, 8, 16, 16, 768)    \
@@ -170,11 +152,10 @@ struct FastColsInfo {
     size_t lds_bytes = 0;
 };
 
-// prefer_T > 0: only the configuration with that tile width
-inline FastColsInfo fast_cols_lookup(int M, int prefer_T = 0) {
+inline FastColsInfo fast_cols_lookup(int M) {
     FastColsInfo r;
 #define FC_X(MM, A, B, C, TT, NTT)                                                   \
-    if (!r.ok && M == MM && (prefer_T <= 0 || prefer_T == TT)) {                     \
+    if (!r.ok && M == MM) {                                                          \
         using Cfg = ColCfg<MM, A, B, C, TT, NTT>;                                    \
         r.ok = true; r.M = MM; r.R1 = A; r.R2 = B; r.R3 = C; r.T = TT; r.NT = NTT;   \
         r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);                          \
@@ -184,11 +165,7 @@ inline FastColsInfo fast_cols_lookup(int M, int prefer_T = 0) {
     return r;
 }
 
-// Paired-row kernel: the one-row-per-workgroup configurations.
-template <class Runner>
-inline bool fast_rows_pair_dispatch(int L, int nz2_needed, Runner&& run) { return fast_rows_rpw1_dispatch(L, nz2_needed, run); }
-
-inline bool fast_cols_length(int M) { return fast_cols_lookup(M).ok; }
+inline bool fast_cols_length(int M, int) { return fast_cols_lookup(M).ok; }
 
 // Forward column kernel (fast_cols_fwd.hpp): same configurations; NZ2 = 3 (pruned, short kernels)
 // or R2 (any input length).  run.template go<Cfg, NZ2>().
@@ -228,21 +205,12 @@ struct FastColsTables {
     Plan1D plan;                   // radices (R1, R2, R3)
     std::vector<c32> tw1, tw2;
     std::vector<PairEntry> pairs;  // positions in the fast plan's order
-    std::vector<int> rowoff;       // M+1: Y row offset feeding LDS position p
-    std::vector<int> tile_row_of;  // M+1: generic spectrum row i -> row of the tiled intermediate
-    std::vector<int> tile_lpos;    // M+1: tile row -> LDS landing position in the output kernel
-    std::vector<int> pair_row_of;  // M+1: generic spectrum row i -> row of the pair-adjacent tile (mode 3)
-    std::vector<int> pair_row_seq; // M+1: spectrum rows sorted by pair_row_of (processing order of the persistent row kernel)
-    // precombined intermediate (fast_rows_pair.hpp): one RowPair per paired-row workgroup, and the
-    // LDS landing position of every tile row
-    std::vector<RowPair> row_pairs;  // M/2 + 1
-    std::vector<int> lpos;           // M
+    std::vector<int> rowoff;       // M+1: row-major Y: row offset feeding LDS position p
+    std::vector<int> pair_row_of;  // M+1: spectrum row i (producer order) -> row of the pair-adjacent tiled intermediate
 };
 
-// row_order (tiled intermediate): 0 = tile rows in the output kernel's LDS order (sequential,
-// conflict-free landing); 1 = rows of workgroups i and i+8 adjacent (half-lines meet in one L2);
-// 2 = spectrum row order (rows i, i+1 adjacent: what the persistent row kernel writes back to back).
-inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& generic, int y_pitch, int row_order = 0) {
+// `producer`: the plan whose digit-reversed order the spectrum rows are produced in.
+inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D& producer, int y_pitch) {
     FastColsTables t;
     t.plan = make_plan1d_seq(fi.M, {fi.R1, fi.R2, fi.R3});
     const int m1 = fi.M / fi.R1;
@@ -252,152 +220,16 @@ inline FastColsTables make_fast_cols_tables(const FastColsInfo& fi, const Plan1D
     t.tw2.assign(t.plan.tw.begin() + s2.tw_off, t.plan.tw.begin() + s2.tw_off + (fi.R2 - 1) * fi.R3);
     t.pairs = make_pair_table(t.plan);
     t.rowoff.assign(fi.M + 1, 0);
-    for (int k = 0; k < fi.M; k++) t.rowoff[t.plan.pos[k]] = generic.pos[k] * y_pitch;
+    for (int k = 0; k < fi.M; k++) t.rowoff[t.plan.pos[k]] = producer.pos[k] * y_pitch;
     t.rowoff[fi.M] = fi.M * y_pitch;
-    // Tiled (not precombined) intermediate: spectrum row i (= workgroup i of the single-row
-    // kernel) goes to tile row r(i) chosen so that workgroups i and i+8 -- same XCD under
-    // round-robin dispatch, running at about the same time -- write ADJACENT 64-byte tile rows,
-    // i.e. the two halves of one 128-byte line meet in that XCD's L2 before going to HBM.
-    t.tile_row_of.assign(fi.M + 1, 0);
-    t.tile_lpos.assign(fi.M + 1, 0);
-    std::vector<int> bin_of_row(fi.M, 0);
-    for (int k = 0; k < fi.M; k++) bin_of_row[generic.pos[k]] = k;
-    const int full = (fi.M / 16) * 16;
-    for (int i = 0; i < fi.M; i++) {
-        int r = t.plan.pos[bin_of_row[i]];
-        if (row_order == 1) {
-            r = i;
-            if (i < full) r = 16 * (i / 16) + 2 * (i % 8) + ((i / 8) % 2);
-        } else if (row_order == 2) {
-            r = i;
-        }
-        t.tile_row_of[i] = r;
-        t.tile_lpos[r] = t.plan.pos[bin_of_row[i]];
-    }
-    t.tile_row_of[fi.M] = fi.M;
-    t.tile_lpos[fi.M] = fi.M;
-    // pair-adjacent tile rows (mode 3): pair p = (bin p, bin M-p) at rows 2p, 2p+1;
+    // pair-adjacent tile rows: pair p = (bin p, bin M-p) at rows 2p, 2p+1;
     // p = 0: (DC, Nyquist); p = M/2: (middle bin, padding)
     t.pair_row_of.assign(fi.M + 1, 0);
     for (int k = 0; k < fi.M; k++) {
         int r = (k <= fi.M / 2) ? 2 * k : 2 * (fi.M - k) + 1;
-        t.pair_row_of[generic.pos[k]] = r;
+        t.pair_row_of[producer.pos[k]] = r;
     }
     t.pair_row_of[fi.M] = 1;
-    {
-        std::vector<int> inv(fi.M + 2, -1);
-        for (int i = 0; i <= fi.M; i++) inv[t.pair_row_of[i]] = i;
-        for (int r = 0; r < fi.M + 2; r++)
-            if (inv[r] >= 0) t.pair_row_seq.push_back(inv[r]);
-    }
-    const int M = fi.M;
-    t.lpos.assign(M, 0);
-    for (int u = 0; u + 1 < M / 2; u++) {   // regular pairs k = u + 1
-        const int k = u + 1;
-        RowPair rp{};
-        rp.rowA = generic.pos[k]; rp.rowB = generic.pos[M - k];
-        rp.outA = 2 * u; rp.outB = 2 * u + 1; rp.kind = 0;
-        double ang = -2.0 * M_PI * (double)k / (double)(2 * M);
-        rp.w = mk((float)std::cos(ang), (float)std::sin(ang));
-        t.row_pairs.push_back(rp);
-        t.lpos[rp.outA] = t.plan.pos[k];
-        t.lpos[rp.outB] = t.plan.pos[M - k];
-    }
-    {   // DC + Nyquist -> Z_0
-        RowPair rp{};
-        rp.rowA = generic.pos[0]; rp.rowB = M; rp.outA = M - 2; rp.outB = -1; rp.kind = 1; rp.w = mk(1.f, 0.f);
-        t.row_pairs.push_back(rp);
-        t.lpos[rp.outA] = t.plan.pos[0];
-    }
-    {   // self-paired middle bin
-        RowPair rp{};
-        rp.rowA = generic.pos[M / 2]; rp.rowB = rp.rowA; rp.outA = M - 1; rp.outB = -1; rp.kind = 2; rp.w = mk(1.f, 0.f);
-        t.row_pairs.push_back(rp);
-        t.lpos[rp.outA] = t.plan.pos[M / 2];
-    }
-    return t;
-}
-
-// ---------------------------------------------------------------------------------------
-// 16-column output kernel (fast_cols_wide.hpp): X(H, R2, R3, R4, NT), transform M = 2H.
-//   M = 2112 = 2 x (6 x 8 x 22): the cfg3 / cfg4 output pass.
-// ---------------------------------------------------------------------------------------
-//   (8 x 12 x 11: the in-register radix is kept small -- the kernel holds a whole half tile plus a
-//    prefetched one in registers and must stay under the 168 VGPRs of 3 waves per SIMD)
-#define FC_FAST_COLW_CONFIGS(X) \
-    X(1056, 8, 12, 11, 768)
-
-struct FastColsWideInfo {
-    bool ok = false;
-    int H = 0, R2 = 0, R3 = 0, R4 = 0, NT = 0;
-    size_t lds_bytes = 0;
-};
-
-inline FastColsWideInfo fast_cols_wide_lookup(int M) {
-    FastColsWideInfo r;
-#define FC_X(HH, A, B, C, NTT)                                              \
-    if (!r.ok && M == 2 * HH) {                                             \
-        using Cfg = ColWideCfg<HH, A, B, C, NTT>;                           \
-        r.ok = true; r.H = HH; r.R2 = A; r.R3 = B; r.R4 = C; r.NT = NTT;    \
-        r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);                 \
-    }
-    FC_FAST_COLW_CONFIGS(FC_X)
-#undef FC_X
-    return r;
-}
-
-template <class Runner>
-inline bool fast_cols_wide_dispatch(int M, Runner&& run) {
-#define FC_X(HH, A, B, C, NTT)                               \
-    if (M == 2 * HH) {                                       \
-        run.template go<ColWideCfg<HH, A, B, C, NTT>>();     \
-        return true;                                         \
-    }
-    FC_FAST_COLW_CONFIGS(FC_X)
-#undef FC_X
-    return false;
-}
-
-struct FastColsWideTables {
-    Plan1D plan;                        // radices (2, R2, R3, R4)
-    std::vector<c32> tw3, twA, twF, wh, wl;
-    std::vector<unsigned> ppA, ppB;
-    std::vector<int> tile_row_of;       // M+1: generic spectrum row i -> row of the 16-column tile
-};
-
-inline FastColsWideTables make_fast_cols_wide_tables(const FastColsWideInfo& fi, const Plan1D& generic) {
-    FastColsWideTables t;
-    const int H = fi.H, M = 2 * H, m2 = H / fi.R2;
-    t.plan = make_plan1d_seq(M, {2, fi.R2, fi.R3, fi.R4});
-    const StageDesc& s1 = t.plan.desc.st[0];   // radix 2, m = H:   w_M^b
-    const StageDesc& s2 = t.plan.desc.st[1];   // radix R2, m = m2: w_H^(b c)
-    const StageDesc& s3 = t.plan.desc.st[2];   // radix R3, m = R4
-    t.twF.assign(t.plan.tw.begin() + s1.tw_off, t.plan.tw.begin() + s1.tw_off + m2);
-    t.twA.assign(t.plan.tw.begin() + s2.tw_off, t.plan.tw.begin() + s2.tw_off + m2);
-    t.tw3.assign(t.plan.tw.begin() + s3.tw_off, t.plan.tw.begin() + s3.tw_off + (fi.R3 - 1) * fi.R4);
-    const int N = 2 * M;
-    for (int i = 0; i < M / 32 + 2; i++) {
-        double a = -2.0 * M_PI * (double)(32 * i) / (double)N;
-        t.wh.push_back(mk((float)std::cos(a), (float)std::sin(a)));
-    }
-    for (int i = 0; i < 32; i++) {
-        double a = -2.0 * M_PI * (double)i / (double)N;
-        t.wl.push_back(mk((float)std::cos(a), (float)std::sin(a)));
-    }
-    const std::vector<int>& pos = t.plan.pos;   // even bins in [0, H), odd bins in [H, 2H)
-    for (int i = 0; i <= H / 2; i++) {          // half A: k = 2i
-        const int k = 2 * i;
-        unsigned a = (unsigned)pos[k], b = (i == 0) ? (unsigned)H : (unsigned)pos[M - k];
-        t.ppA.push_back(a | (b << 16));
-    }
-    for (int i = 0; i < H / 2; i++) {           // half B: k = 2i + 1
-        const int k = 2 * i + 1;
-        unsigned a = (unsigned)(pos[k] - H), b = (unsigned)(pos[M - k] - H);
-        t.ppB.push_back(a | (b << 16));
-    }
-    t.tile_row_of.assign(M + 1, 0);
-    for (int k = 0; k < M; k++) t.tile_row_of[generic.pos[k]] = (k & 1) ? pos[k] + 1 : pos[k];
-    t.tile_row_of[M] = H;
     return t;
 }
 

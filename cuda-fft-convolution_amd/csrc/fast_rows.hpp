@@ -79,7 +79,7 @@ struct FastRowsArgs {
     const int* y_row_of;
     int y_tile_elems;        // (M+1) * TL
     int y_tile_shift;        // log2(TL)
-    const int* row_seq;      // persistent variant: j-th row to process (nullptr: identity)
+    unsigned long long* timeline;  // FC_ROWS_TIMELINE builds only: per-phase wall-clock stamps of one workgroup (else unused)
 };
 
 template <class C, bool MULTIF>
@@ -292,209 +292,6 @@ FC_HD void fast_rows_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, 
             }
         });
     });
-}
-
-// ---------------------------------------------------------------------------------------
-// Persistent variant: a workgroup walks a contiguous run of work items (kernel n, spectrum row i)
-// -- item = n*rows + i -- instead of owning one.  What it buys:
-//   * the loads of the NEXT item (kernel row + image-spectrum row) are issued into the registers
-//     that just went dead (after P1 / P3) and fly during P4, P5 and the next P1, P2;
-//   * consecutive rows i, i+1 of one kernel are written by the same CU a few microseconds
-//     apart, so with the tiled intermediate (64 bytes per row and 8-column tile) the two halves
-//     of every 128-byte line meet in that XCD's L2 and leave as one full line;
-//   * no partially filled last wave of workgroups.
-// F > 1 keeps the simple flow (loads at the top of every feature).
-// ---------------------------------------------------------------------------------------
-template <class C, int NZ2, bool MULTIF, class Ctx>
-FC_HD void fast_rows_persist_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int rows, int item0, int item1) {
-    static_assert(C::RPW == 1, "the persistent variant handles one row per workgroup");
-    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1;
-    constexpr int XR = row_x_rounds<C>();
-    using State = RowState<C, MULTIF>;
-    const int nF = MULTIF ? g.F : 1;
-    c32* tw2 = lds + L;
-    const int kw = g.kw;
-    if (item0 >= item1) return;
-
-    // item = kernel*rows + j; the j-th row processed is row_seq[j] (tile order: consecutive
-    // items write adjacent rows of the tiled intermediate)
-    auto issue_loads = [&](int t, State& st, int item, int f) {
-        const int kernel = item / rows;
-        const int row = FC_UNIFORM(g.row_seq ? g.row_seq[item - kernel * rows] : item - kernel * rows);
-        const c32* arow = g.A + (size_t)kernel * g.a_kernel_stride + (size_t)f * g.a_feat_stride + (size_t)row * g.a_pitch;
-        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)row * g.s_pitch;
-        static_for<0, XR>([&](auto r_) {
-            constexpr int r = decltype(r_)::value;
-            int j = t + NT * r;
-            st.x[r] = (j < kw) ? arow[j] : mk(0.f, 0.f);
-        });
-        if (t < C::NB3) {
-            static_for<0, R3 / 2>([&](auto h_) {
-                constexpr int h = decltype(h_)::value;
-                c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + t) * 2);
-                st.s[2 * h] = v.a;
-                st.s[2 * h + 1] = v.b;
-            });
-        }
-    };
-
-    // prologue: first item's loads in flight, then the stage-2 twiddles into LDS
-    ctx.phase([&](int t, State& st) {
-        issue_loads(t, st, item0, 0);
-        for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
-    });
-
-    for (int item = item0; item < item1; item++) {
-        const int kernel = item / rows;
-        const int row = FC_UNIFORM(g.row_seq ? g.row_seq[item - kernel * rows] : item - kernel * rows);
-        for (int f = 0; f < nF; f++) {
-            if (MULTIF && f > 0) ctx.phase_nosync([&](int t, State& st) { issue_loads(t, st, item, f); });
-
-            // P1: forward stage 1, pruned
-            ctx.phase([&](int t, State& st) {
-                static_for<0, XR>([&](auto r_) {
-                    constexpr int r = decltype(r_)::value;
-                    int j = t + NT * r;
-                    if (j < kw) {
-                        c32 p[R1];
-                        power_chain<R1>(g.tw1[j], p);
-                        lds[j] = st.x[r];
-                        static_for<1, R1>([&](auto c_) {
-                            constexpr int c = decltype(c_)::value;
-                            lds[c * m1 + j] = cmul(st.x[r], p[c]);
-                        });
-                    }
-                });
-            });
-
-            // P2: forward stage 2
-            ctx.phase([&](int t, State&) {
-                static_for<0, C::RND2>([&](auto r_) {
-                    constexpr int r = decltype(r_)::value;
-                    int u = t + NT * r;
-                    if (u < C::NB2) {
-                        int c1 = u / R3, b = u - c1 * R3;
-                        c32* p = lds + c1 * m1 + b;
-                        c32 v[R2];
-                        static_for<0, R2>([&](auto a_) {
-                            constexpr int a = decltype(a_)::value;
-                            if constexpr (a < NZ2) v[a] = (a * R3 + b < kw) ? p[a * R3] : mk(0.f, 0.f);
-                            else v[a] = mk(0.f, 0.f);
-                        });
-                        Dft<R2, -1>::run(v);
-                        p[0] = v[0];
-                        static_for<1, R2>([&](auto c_) {
-                            constexpr int c = decltype(c_)::value;
-                            p[c * R3] = cmul(v[c], tw2[(c - 1) * R3 + b]);
-                        });
-                    }
-                });
-            });
-
-            // P3: forward stage 3, product, (feature sum,) inverse stage 3 -- in registers
-            const bool last = (f == nF - 1);
-            ctx.phase([&](int t, State& st) {
-                if (t < C::NB3) {
-                    c32* p = lds + t * R3;
-                    c32 v[R3];
-                    static_for<0, R3 / 2>([&](auto h_) {
-                        constexpr int h = decltype(h_)::value;
-                        c32x2 w = *reinterpret_cast<const c32x2*>(p + 2 * h);
-                        v[2 * h] = w.a;
-                        v[2 * h + 1] = w.b;
-                    });
-                    Dft<R3, -1>::run(v);
-                    if constexpr (!MULTIF) {
-                        static_for<0, R3>([&](auto a_) {
-                            constexpr int a = decltype(a_)::value;
-                            v[a] = cmul(v[a], st.s[a]);
-                        });
-                    } else {
-                        static_for<0, R3>([&](auto a_) {
-                            constexpr int a = decltype(a_)::value;
-                            c32 q = cmul(v[a], st.s[a]);
-                            st.acc[a] = (f == 0) ? q : st.acc[a] + q;
-                            v[a] = st.acc[a];
-                        });
-                    }
-                    if (last) {
-                        Dft<R3, +1>::run(v);
-                        static_for<0, R3 / 2>([&](auto h_) {
-                            constexpr int h = decltype(h_)::value;
-                            c32x2 w;
-                            w.a = v[2 * h];
-                            w.b = v[2 * h + 1];
-                            *reinterpret_cast<c32x2*>(p + 2 * h) = w;
-                        });
-                    }
-                }
-            });
-        }
-
-        // P4: inverse stage 2
-        ctx.phase([&](int t, State&) {
-            static_for<0, C::RND2>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
-                int u = t + NT * r;
-                if (u < C::NB2) {
-                    int c1 = u / R3, b = u - c1 * R3;
-                    c32* p = lds + c1 * m1 + b;
-                    c32 v[R2];
-                    v[0] = p[0];
-                    static_for<1, R2>([&](auto c_) {
-                        constexpr int c = decltype(c_)::value;
-                        v[c] = cmulc(p[c * R3], tw2[(c - 1) * R3 + b]);
-                    });
-                    Dft<R2, +1>::run(v);
-                    static_for<0, R2>([&](auto a_) {
-                        constexpr int a = decltype(a_)::value;
-                        p[a * R3] = v[a];
-                    });
-                }
-            });
-        });
-
-        // The registers that held this item's kernel row and spectrum row are dead since P3: the
-        // next item's loads go into them now -- after the register-hungry P4 -- and fly during P5
-        // and the next P1, P2 (the same live range a row has in the plain kernel).
-        // (unconditional -- the last item reloads itself -- so that the old values are provably dead
-        // during P4 and the registers are shared)
-        {
-            const int nxt = (item + 1 < item1) ? item + 1 : item;
-            ctx.phase_nosync([&](int t, State& st) { issue_loads(t, st, nxt, 0); });
-        }
-
-        // P5: inverse stage 1 straight to global memory; the closing barrier protects the LDS
-        // row against the next item's P1
-        const bool tiled = g.y_row_of != nullptr;
-        c32* yrow = g.Y + (size_t)kernel * g.y_kernel_stride +
-                    (tiled ? ((size_t)FC_UNIFORM(g.y_row_of[row]) << g.y_tile_shift) : (size_t)row * g.y_pitch);
-        ctx.phase([&](int t, State&) {
-            FC_NOUNROLL
-            for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the next item's rows are in registers
-                int j = t + NT * r;
-                if (j < C::NB1) {
-                    c32 p[R1];
-                    power_chain<R1>(g.tw1[j], p);
-                    c32 v[R1];
-                    v[0] = lds[j];
-                    static_for<1, R1>([&](auto c_) {
-                        constexpr int c = decltype(c_)::value;
-                        v[c] = cmulc(lds[c * m1 + j], p[c]);
-                    });
-                    Dft<R1, +1>::run(v);
-                    static_for<0, R1>([&](auto a_) {
-                        constexpr int a = decltype(a_)::value;
-                        int w = j + a * m1;
-                        if (w < g.wout) {
-                            if (tiled) yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))] = v[a];
-                            else yrow[w] = v[a];
-                        }
-                    });
-                }
-            }
-        });
-    }
 }
 
 }  // namespace fc

@@ -25,7 +25,7 @@
 #define FC_ROWS_TIMELINE_WG 1000
 #endif
 #if FC_ROWS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
-#define FC_ROWS_STAMP(slot) do { if (group == FC_ROWS_TIMELINE_WG && kernel0 == 0 && threadIdx.x == 0 && g.row_seq && m < 16) reinterpret_cast<unsigned long long*>(const_cast<int*>(g.row_seq))[m * 8 + (slot)] = wall_clock64(); } while (0)
+#define FC_ROWS_STAMP(slot) do { if (group == FC_ROWS_TIMELINE_WG && kernel0 == 0 && threadIdx.x == 0 && g.timeline && m < 16) g.timeline[m * 8 + (slot)] = wall_clock64(); } while (0)
 #else
 #define FC_ROWS_STAMP(slot) ((void)0)
 #endif

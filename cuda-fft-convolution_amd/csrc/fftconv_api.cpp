@@ -12,11 +12,13 @@
 #include <deque>
 #include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/fftconv.h"
+#include "api_internal.hpp"
 #include "kernels.hpp"
 #include "pipeline.hpp"
 
@@ -34,6 +36,37 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+
+}  // namespace
+
+namespace fc {
+int api_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+std::string api_last_error() { return g_last_error; }
+void api_set_last_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace fc
+
+namespace {
+
+// live plans of this process (fftconv_plan_is_live: the MEX gateways validate handles with it)
+std::mutex g_live_mutex;
+std::set<const fftconv_plan*> g_live_plans;
+
+PlanTuning tuning_from(const fftconv_plan_options* o) {
+    PlanTuning t;
+    if (!o || o->struct_size < sizeof(fftconv_plan_options)) return t;
+    t.path_mode = o->kernel_path == 1 ? 0 : o->kernel_path == 2 ? 1 : 2;
+    t.rows_group = o->rows_group <= 0 ? -1 : o->rows_group;
+    t.max_transform = o->max_transform > 0 ? o->max_transform : 0;
+    return t;
 }
 
 #define HIP_TRY(call)                                                                              \
@@ -239,7 +272,8 @@ struct fftconv_plan {
     DevBuf<PairEntry> pairs;
     DevBuf<c32> S;     // image spectrum (own buffer)
     c32* Sx = nullptr; // caller-owned spectrum buffer, if any
-    c32* spec() const { return Sx ? Sx : S.p; }
+    c32* spec() const { return Sx ? Sx : S.p; }   // S is allocated by the first use that needs it (ensure_spectrum)
+    int ensure_spectrum() { return Sx ? 0 : S.ensure(g.spectrum_elems()); }
     DevBuf<c32> A;     // kernel column spectra of the current chunk
     DevBuf<c32> Y;     // intermediate of the current map batch
     DevBuf<float> K;   // packed kernels staged on the device
@@ -257,11 +291,7 @@ struct fftconv_plan {
     DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
-    DevBuf<int> fc_rowoff, fc_tile_row_of, fc_lpos, fc_tile_lpos, fc_pair_row_of, fc_pair_row_seq;
-    DevBuf<RowPair> fc_row_pairs;
-    DevBuf<c32> cw_tw3, cw_twA, cw_twF, cw_wh, cw_wl;
-    DevBuf<unsigned> cw_ppA, cw_ppB;
-    DevBuf<int> cw_tile_row_of;
+    DevBuf<int> fc_rowoff, fc_pair_row_of;
     int num_cus = 256;
     long opt_batch_maps = 0;
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
@@ -331,9 +361,7 @@ struct fftconv_plan {
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); OC.release(); I.release();
         fr_tw1.release(); fr_tw2.release(); fr_map.release();
-        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_tile_row_of.release(); fc_lpos.release(); fc_row_pairs.release(); fc_tile_lpos.release(); fc_pair_row_of.release(); fc_pair_row_seq.release();
-        cw_tw3.release(); cw_twA.release(); cw_twF.release(); cw_wh.release(); cw_wl.release();
-        cw_ppA.release(); cw_ppB.release(); cw_tile_row_of.release();
+        fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_pair_row_of.release();
     }
 };
 
@@ -539,15 +567,12 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
         for (int y0 = 0; y0 < na; y0 += nbY) {
             const int ny = std::min(nbY, na - y0);
             if (int rc = p->prof_begin(PK_SPECTRAL, ny)) return rc;
-            if (g.y_pre()) {
-                FastRowsPairArgs fa = fast_rows_pair_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
-                HIP_TRY(launch_fast_rows_pair(g.Lw, fast_rows_nz2(g, kw), fa, g.M / 2 + 1, ny, p->stream));
-            } else if (g.rows_group_for(ny, p->num_cus) > 1) {
+            if (g.rows_group_for(ny, p->num_cus) > 1) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_fast_rows_multi(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_group_for(ny, p->num_cus), p->stream));
             } else if (g.fast_rows.ok) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
-                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_persistent ? 4 * p->num_cus : 0, g.rows_wg_order, p->stream));
+                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_wg_order, p->stream));
             } else {
                 SpectralRowsArgs sa = spectral_rows_args(g, p->t, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
@@ -561,10 +586,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
                 else HIP_TRY(hipStreamWaitEvent(p->stream, p->ring->copy_done[buf], 0));
             }
             if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
-            if (g.use_wide()) {
-                FastColsWideArgs fa = fast_cols_wide_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
-                HIP_TRY(launch_fast_cols_wide(g.M, fa, p->num_cus, p->stream));
-            } else if (g.fast_cols.ok) {
+            if (g.fast_cols.ok) {
                 FastColsArgs fa = fast_cols_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
                 HIP_TRY(launch_fast_cols(g.M, g.fast_cols.T, fa, p->num_cus, p->stream));
             } else {
@@ -630,9 +652,9 @@ int check_thread_size(const double* thread_size, int n_thread_size) {
 // and the blocks partition the image).  The block spectra are computed once and kept; kernels are
 // processed in chunks that fit a few GiB of device maps.
 int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int mkw, int n, const float* const* kernels, const int* kh,
-                          const int* kw, int gpu_id, float* const* out) {
+                          const int* kw, int gpu_id, float* const* out, const fftconv_plan_options* options) {
     int limit = 4224;
-    if (const char* e = getenv("FFTCONV_MAX_TRANSFORM")) { const int v = atoi(e); if (v > 0) limit = std::min(limit, v); }
+    if (options && options->struct_size >= sizeof(fftconv_plan_options) && options->max_transform > 0) limit = std::min(limit, options->max_transform);
     for (int k = 0; k < n; k++)
         if (kh[k] > mkh || kw[k] > mkw)
             return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel %dx%d exceeds MAX_KERNEL %dx%d (block-wise path)", kh[k], kw[k], mkh, mkw);
@@ -645,7 +667,7 @@ int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int m
     int Bh = 0, Bw = 0, rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
     for (int c = 0; c < 3 && !sub; c++) {
         Bh = cand[c][0]; Bw = cand[c][1];
-        rc = fftconv_plan_create(&sub, Bh, Bw, F, mkh, mkw, gpu_id, nullptr);
+        rc = fftconv_plan_create_ex(&sub, Bh, Bw, F, mkh, mkw, gpu_id, nullptr, options);
         if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) return rc;
     }
     if (!sub) return rc;
@@ -719,6 +741,16 @@ int fftconv_device_count(int* count) {
 
 int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature_dim, int max_kernel_h,
                         int max_kernel_w, int gpu_id, void* hip_stream) {
+    return fftconv_plan_create_ex(plan, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, hip_stream, nullptr);
+}
+
+int fftconv_plan_is_live(const fftconv_plan* plan) {
+    std::lock_guard<std::mutex> lk(g_live_mutex);
+    return g_live_plans.count(plan) ? 1 : 0;
+}
+
+int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feature_dim, int max_kernel_h,
+                           int max_kernel_w, int gpu_id, void* hip_stream, const fftconv_plan_options* options) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     *plan = nullptr;
     if (data_h < 1 || data_w < 1 || feature_dim < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
@@ -729,21 +761,16 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
     if (gpu_id >= ndev) return fail(FFTCONV_ERR_NO_DEVICE, "gpu_id %d out of range (%d devices)", gpu_id, ndev);
     fftconv_plan* p = new (std::nothrow) fftconv_plan();
     if (!p) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
-    int path_mode = 2;   // FFTCONV_PATH_MODE: tests and A/B runs only (pipeline.hpp Geometry::path_mode)
-    if (const char* e = getenv("FFTCONV_PATH_MODE")) path_mode = atoi(e);
-    if (path_mode < 0 || path_mode > 3) path_mode = 2;
-    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, path_mode)) {
+    if (options && options->struct_size < sizeof(fftconv_plan_options)) {
+        delete p;
+        return fail(FFTCONV_ERR_INVALID_ARG, "fftconv_plan_options.struct_size is not set");
+    }
+    const PlanTuning tune = tuning_from(options);
+    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, tune)) {
         delete p;
         return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
-                    "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform", data_h, data_w,
-                    feature_dim, max_kernel_h, max_kernel_w);
-    }
-    if (const char* e = getenv("FFTCONV_MAX_TRANSFORM")) {   // tests: make modest sizes take the block-wise path
-        const int lim = atoi(e);
-        if (lim > 0 && (p->g.Lh > lim || p->g.Lw > lim)) {
-            delete p;
-            return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "transform %dx%d exceeds FFTCONV_MAX_TRANSFORM=%d", data_h, data_w, lim);
-        }
+                    "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform%s", data_h, data_w,
+                    feature_dim, max_kernel_h, max_kernel_w, tune.max_transform > 0 ? " within max_transform" : "");
     }
     p->gpu_id = gpu_id;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -755,7 +782,6 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
         if ((rc = p->tw_m.ensure(p->t.pm.tw.size()))) break;
         if ((rc = p->tw_w.ensure(p->t.pw.tw.size()))) break;
         if ((rc = p->pairs.ensure(p->t.pairs.size()))) break;
-        if ((rc = p->S.ensure(p->g.spectrum_elems()))) break;
         auto cp = [&](void* dst, const void* src, size_t bytes) -> int {
             HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
             return 0;
@@ -785,43 +811,9 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
             p->d.fc_tw2 = p->fc_tw2.p;
             p->d.fc_pairs = p->fc_pairs.p;
             p->d.fc_rowoff = p->fc_rowoff.p;
-            if ((rc = p->fc_tile_row_of.ensure(ft.tile_row_of.size()))) break;
-            if ((rc = cp(p->fc_tile_row_of.p, ft.tile_row_of.data(), ft.tile_row_of.size() * sizeof(int)))) break;
-            p->d.fc_tile_row_of = p->fc_tile_row_of.p;
-            if ((rc = p->fc_lpos.ensure(ft.lpos.size()))) break;
-            if ((rc = p->fc_row_pairs.ensure(ft.row_pairs.size()))) break;
-            if ((rc = cp(p->fc_lpos.p, ft.lpos.data(), ft.lpos.size() * sizeof(int)))) break;
-            if ((rc = cp(p->fc_row_pairs.p, ft.row_pairs.data(), ft.row_pairs.size() * sizeof(RowPair)))) break;
-            p->d.fc_lpos = p->fc_lpos.p;
-            if ((rc = p->fc_tile_lpos.ensure(ft.tile_lpos.size()))) break;
-            if ((rc = cp(p->fc_tile_lpos.p, ft.tile_lpos.data(), ft.tile_lpos.size() * sizeof(int)))) break;
-            p->d.fc_tile_lpos = p->fc_tile_lpos.p;
             if ((rc = p->fc_pair_row_of.ensure(ft.pair_row_of.size()))) break;
             if ((rc = cp(p->fc_pair_row_of.p, ft.pair_row_of.data(), ft.pair_row_of.size() * sizeof(int)))) break;
             p->d.fc_pair_row_of = p->fc_pair_row_of.p;
-            if ((rc = p->fc_pair_row_seq.ensure(ft.pair_row_seq.size()))) break;
-            if ((rc = cp(p->fc_pair_row_seq.p, ft.pair_row_seq.data(), ft.pair_row_seq.size() * sizeof(int)))) break;
-            p->d.fc_pair_row_seq = p->fc_pair_row_seq.p;
-            p->d.fc_row_pairs = p->fc_row_pairs.p;
-        }
-        if (p->g.fast_colw.ok) {
-            const FastColsWideTables& fw = p->t.fcw;
-            auto up = [&](auto& buf, const auto& vec) -> int {
-                if (int r = buf.ensure(vec.size())) return r;
-                return cp(buf.p, vec.data(), vec.size() * sizeof(vec[0]));
-            };
-            if ((rc = up(p->cw_tw3, fw.tw3))) break;
-            if ((rc = up(p->cw_twA, fw.twA))) break;
-            if ((rc = up(p->cw_twF, fw.twF))) break;
-            if ((rc = up(p->cw_wh, fw.wh))) break;
-            if ((rc = up(p->cw_wl, fw.wl))) break;
-            if ((rc = up(p->cw_ppA, fw.ppA))) break;
-            if ((rc = up(p->cw_ppB, fw.ppB))) break;
-            if ((rc = up(p->cw_tile_row_of, fw.tile_row_of))) break;
-            p->d.cw_tw3 = p->cw_tw3.p; p->d.cw_twA = p->cw_twA.p; p->d.cw_twF = p->cw_twF.p;
-            p->d.cw_wh = p->cw_wh.p; p->d.cw_wl = p->cw_wl.p;
-            p->d.cw_ppA = p->cw_ppA.p; p->d.cw_ppB = p->cw_ppB.p;
-            p->d.cw_tile_row_of = p->cw_tile_row_of.p;
         }
         if (p->g.fast_rows.ok) {
             const FastRowsTables& fr = p->t.fr;
@@ -841,12 +833,17 @@ int fftconv_plan_create(fftconv_plan** plan, int data_h, int data_w, int feature
         delete p;
         return rc;
     }
+    { std::lock_guard<std::mutex> lk(g_live_mutex); g_live_plans.insert(p); }
     *plan = p;
     return 0;
 }
 
 int fftconv_plan_destroy(fftconv_plan* plan) {
     if (!plan) return 0;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mutex);
+        if (!g_live_plans.erase(plan)) return fail(FFTCONV_ERR_INVALID_ARG, "not a live plan");
+    }
     (void)hipSetDevice(plan->gpu_id);
     (void)hipStreamSynchronize(plan->stream);
     plan->release_all();
@@ -887,6 +884,7 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         dimg = p->I.p;
     }
     // (with the fast row kernel the w-pass stores the spectrum directly in that kernel's register order)
+    if (int rc = p->ensure_spectrum()) return rc;
     c32* sgen = p->spec();
     if (int rc = p->prof_begin(PK_IMAGE_COLS, g.F)) return rc;
     if (g.fast_fwd) {
@@ -909,6 +907,8 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
 
 int fftconv_plan_spectrum(fftconv_plan* plan, void** device_ptr, size_t* bytes) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (int rc = use_device(plan)) return rc;
+    if (int rc = plan->ensure_spectrum()) return rc;
     if (device_ptr) *device_ptr = plan->spec();
     if (bytes) *bytes = plan->g.spectrum_elems() * sizeof(c32);
     return 0;
@@ -928,6 +928,7 @@ int fftconv_plan_use_spectrum_buffer(fftconv_plan* plan, void* device_ptr, size_
 
 int fftconv_plan_mark_spectrum_valid(fftconv_plan* plan) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (!plan->spec()) return fail(FFTCONV_ERR_NO_IMAGE, "the plan has no spectrum buffer yet (fftconv_plan_spectrum / fftconv_plan_use_spectrum_buffer)");
     plan->have_image = true;
     return 0;
 }
@@ -972,9 +973,7 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
     // mid-loop and leaks: SURVEY D3)
     for (int k = 0; k < n_kernel; k++) {
         if (!kernels[k] || !out[k]) return fail(FFTCONV_ERR_INVALID_ARG, "kernel or output %d is NULL", k);
-        if (kernel_h[k] < 1 || kernel_w[k] < 1 || kernel_h[k] > g.fft_h || kernel_w[k] > g.fft_w)
-            return fail(FFTCONV_ERR_KERNEL_SHAPE,
-                        "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+        if (int rc = check_kernel_size(p, kernel_h[k], kernel_w[k])) return rc;
     }
     // groups of consecutive kernels of equal size
     int k0 = 0;
@@ -1020,6 +1019,11 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "rows_group")) { plan->g.rows_group = value <= 0 ? -1 : (int)value; return 0; }
+#if FC_ROWS_TIMELINE || FC_COLS_TIMELINE
+    // diagnostic builds only (tools/rows_timeline.py, tools/cols_timeline.py): device buffer one workgroup stamps
+    if (!strcmp(name, "timeline_ptr")) { plan->d.timeline = reinterpret_cast<unsigned long long*>((uintptr_t)value); return 0; }
+#endif
     if (!strcmp(name, "output_region")) {
         const Geometry& g = plan->g;
         int oh = g.fft_h, ow = g.fft_w, fh = 0, fw = 0;
@@ -1065,6 +1069,14 @@ int fftconv_convolution_fft(const float* data, int data_h, int data_w, int featu
                             int max_kernel_w, int n_kernel, const float* const* kernels, const int* kernel_h,
                             const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
                             int gpu_id, float* const* out, int* fft_h, int* fft_w) {
+    return fftconv_convolution_fft_ex(data, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, n_kernel, kernels, kernel_h,
+                                      kernel_w, kernel_f, thread_size, n_thread_size, gpu_id, out, fft_h, fft_w, nullptr);
+}
+
+int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int feature_dim, int max_kernel_h,
+                               int max_kernel_w, int n_kernel, const float* const* kernels, const int* kernel_h,
+                               const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
+                               int gpu_id, float* const* out, int* fft_h, int* fft_w, const fftconv_plan_options* options) {
     // argument checks in the reference's order (src/cudaConvolutionFFT.cu:45-89)
     if (!data || data_h < 1 || data_w < 1 || feature_dim < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
     if (n_kernel < 0 || (n_kernel > 0 && (!kernels || !kernel_h || !kernel_w || !out)))
@@ -1078,11 +1090,11 @@ int fftconv_convolution_fft(const float* data, int data_h, int data_w, int featu
     if (fft_h) *fft_h = fft_size16(data_h + max_kernel_h - 1);
     if (fft_w) *fft_w = fft_size16(data_w + max_kernel_w - 1);
     fftconv_plan* p = nullptr;
-    if (int rc = fftconv_plan_create(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr)) {
+    if (int rc = fftconv_plan_create_ex(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr, options)) {
         // too large for one single-pass plan: block-wise (overlap-add) over ordinary plans
         if (rc == FFTCONV_ERR_UNSUPPORTED_SIZE && n_kernel > 0)
             return tiled_convolution_fft(data, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, n_kernel, kernels, kernel_h,
-                                         kernel_w, gpu_id, out);
+                                         kernel_w, gpu_id, out, options);
         return rc;
     }
     int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);

@@ -5,10 +5,10 @@
 namespace fc {
 namespace {
 
-template <class Cfg, int MODE>
+template <class Cfg, bool TILED>
 __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols(FastColsArgs a) {
-    DevPhaseCtx<std::conditional_t<MODE == 3, ColPairState<Cfg>, ColState<Cfg>>> ctx;
-    fast_cols_body<Cfg, MODE>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
+    DevPhaseCtx<std::conditional_t<TILED, ColPairState<Cfg>, ColState<Cfg>>> ctx;
+    fast_cols_body<Cfg, TILED>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 struct FastColsLauncher {
@@ -18,24 +18,20 @@ struct FastColsLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg>
     void go() {
-        if (a.y_precombined) {
-            if constexpr (Cfg::T == 8) launch<Cfg, 2>();   // precombined tiles are 8 columns wide
-            else err = hipErrorInvalidValue;
-        } else if (a.y_tiled && a.y_pair_rows) launch<Cfg, 3>();
-        else if (a.y_tiled) launch<Cfg, 1>();
-        else launch<Cfg, 0>();
+        if (a.y_tiled) launch<Cfg, true>();
+        else launch<Cfg, false>();
     }
-    template <class Cfg, int PRE>
+    template <class Cfg, bool TILED>
     void launch() {
         static unsigned long long attr_mask = 0;
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
-        err = ensure_lds_attr(k_fast_cols<Cfg, PRE>, attr_mask);
+        err = ensure_lds_attr(k_fast_cols<Cfg, TILED>, attr_mask);
         if (err != hipSuccess) return;
         // persistent: as many workgroups as fit at once (LDS-limited), one or two per CU
         const int per_cu = (int)((size_t)(160 * 1024) / lds) < 768 / Cfg::NT ? (int)((size_t)(160 * 1024) / lds) : 768 / Cfg::NT;
         const int want = max_wg * (per_cu < 1 ? 1 : per_cu);
         const int grid = a.ntiles < want ? a.ntiles : want;
-        hipLaunchKernelGGL((k_fast_cols<Cfg, PRE>), dim3(grid), dim3(Cfg::NT), lds, s, a);
+        hipLaunchKernelGGL((k_fast_cols<Cfg, TILED>), dim3(grid), dim3(Cfg::NT), lds, s, a);
         err = hipGetLastError();
     }
 };

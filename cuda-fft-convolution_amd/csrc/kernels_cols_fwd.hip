@@ -1,32 +1,9 @@
-// kernels_cols_fwd.hip -- the forward-column kernel (fast_cols_fwd.hpp) and the 16-column output kernel (fast_cols_wide.hpp: A/B)
+// kernels_cols_fwd.hip -- the forward-column kernel (fast_cols_fwd.hpp)
 // (one of the kernels_*.hip translation units; see kernels_common.hpp).
 #include "kernels_common.hpp"
 
 namespace fc {
 namespace {
-
-template <class Cfg>
-__global__ void __launch_bounds__(Cfg::NT, Cfg::NT / 256) k_fast_cols_wide(FastColsWideArgs a) {
-    DevPhaseCtx<ColWideState<Cfg>> ctx;
-    fast_cols_wide_body<Cfg>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, (int)gridDim.x);
-}
-
-struct FastColsWideLauncher {
-    const FastColsWideArgs& a;
-    int num_cus;
-    hipStream_t s;
-    hipError_t err = hipSuccess;
-    template <class Cfg>
-    void go() {
-        static unsigned long long attr_mask = 0;
-        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
-        err = ensure_lds_attr(k_fast_cols_wide<Cfg>, attr_mask);
-        if (err != hipSuccess) return;
-        const int grid = a.ntiles < num_cus ? a.ntiles : num_cus;   // persistent, one workgroup per CU
-        hipLaunchKernelGGL((k_fast_cols_wide<Cfg>), dim3(grid), dim3(Cfg::NT), lds, s, a);
-        err = hipGetLastError();
-    }
-};
 
 template <class Cfg, int NZ2>
 __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_cols_fwd(FastColsFwdArgs a) {
@@ -59,13 +36,6 @@ hipError_t launch_fast_cols_fwd(int M, int T, bool pruned, const FastColsFwdArgs
     if (a.ntiles <= 0) return hipSuccess;
     FastColsFwdLauncher l{a, num_cus, s};
     if (!fast_cols_fwd_dispatch(M, T, pruned, l)) return hipErrorInvalidValue;
-    return l.err;
-}
-
-hipError_t launch_fast_cols_wide(int M, const FastColsWideArgs& a, int num_cus, hipStream_t s) {
-    if (a.ntiles <= 0) return hipSuccess;
-    FastColsWideLauncher l{a, num_cus, s};
-    if (!fast_cols_wide_dispatch(M, l)) return hipErrorInvalidValue;
     return l.err;
 }
 

@@ -4,7 +4,6 @@
 #pragma once
 #include <algorithm>
 #include <cstddef>
-#include <cstdlib>
 
 #include "fast_paths.hpp"
 #include "kernels_body.hpp"
@@ -15,6 +14,20 @@ namespace fc {
 constexpr size_t FC_LDS_BUDGET = 160 * 1024;  // bytes of LDS one workgroup may claim (gfx950 CU)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Choices fixed at plan creation (include/fftconv.h: fftconv_plan_options).  The product reads no
+// environment variables; tests and A/B runs pass these through fftconv_plan_create_ex.
+struct PlanTuning {
+    // 0 generic kernels only; 1 specialised kernels with a row-major intermediate; 2 (default)
+    // specialised kernels with the tiled, pair-adjacent intermediate
+    int path_mode = 2;
+    // maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1): -1 = chosen per
+    // launch (rows_group_for), 0 / 1 = plain one-map kernel, > 1 = fixed
+    int rows_group = -1;
+    // largest transform length a plan may use (0 = whatever fits the LDS); larger problems are left
+    // to the block-wise path of the one-shot entry
+    int max_transform = 0;
+};
 
 struct Geometry {
     // problem (src/cudaConvolutionFFT.cu:92-112)
@@ -33,31 +46,19 @@ struct Geometry {
     bool exact_window = false; // Lh == fft_h && Lw == fft_w: circular modulus equals the reference's
     FastRowsInfo fast_rows;    // specialised spectral-row kernel, if one exists for (Lw, max_kw)
     FastColsInfo fast_cols;    // specialised output kernel, if one exists for M
-    FastColsWideInfo fast_colw; // its 16-column variant (tiled intermediate only)
     bool fast_fwd = false;     // forward column transforms (image, kernels) by fast_cols_fwd.hpp: the
                                // spectrum rows are then in the fast plan's order, not the generic plan's
-    // precombined + tiled intermediate: both hot kernels fast, 8-column tiles (fast_rows_pair.hpp)
-    bool y_pre() const { return path_mode >= 3 && fast_rows.ok && fast_rows.RPW == 1 && fast_cols.ok && fast_cols.T == 8 && exact_window; }
-    // 0 generic kernels only; 1 fast kernels, row-major intermediate; 2 (default) + tiled
-    // intermediate; 3 paired rows / precombined intermediate (measured slower on MI355X: the
-    // 6-wave workgroups hide latency worse).  The other modes exist for tests and A/B runs.
-    int path_mode = 2;
-    // tiled intermediate: both hot kernels fast and the window a whole number of layout tiles
+    int path_mode = 2;         // PlanTuning::path_mode
+    // tiled intermediate [w / 16][row][16] (one 128-byte line per row and tile), rows of bins
+    // (k, M-k) adjacent so that the output kernel merges them while landing: both hot kernels
+    // specialised and the window a whole number of layout tiles
+    static constexpr int y_tile_w = 16;
+    static constexpr int y_tile_shift = 4;
     bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
-    // tiled with the rows of bins (k, M-k) adjacent: the output kernel merges them while landing
-    bool y_pair_rows() const { return y_tiled() && pair_rows_on && !use_wide(); }
-    bool pair_rows_on = true;
-    int tile_rows() const { return y_pair_rows() ? M + 2 : rows; }
-    // the 16-column output kernel reads whole 128-byte rows of the 16-column tiled intermediate
-    bool use_wide() const { return y_tiled() && fast_colw.ok && y_tile_w == 16; }
-    int y_tile_w = 16;         // columns per tile of the tiled intermediate (8 or 16); 16 = one 128-byte line per row
-    int y_tile_shift() const { return y_tile_w == 16 ? 4 : 3; }
-    int y_row_order = 0;       // see make_fast_cols_tables
-    int rows_wg_order = 0;     // workgroup order of the fast row kernel (kernels_rows.hip: k_fast_rows); F = 1: 1, 2 measured equal, F > 1: 2 by default
-    // maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1): -1 = chosen per
-    // launch (rows_group_for), 0 / 1 = plain one-map kernel, > 1 = fixed (A/B runs)
-    int rows_group = -1;
-    bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && F == 1 && fast_rows.ok && !y_pre() && !rows_persistent; }
+    int tile_rows() const { return y_tiled() ? M + 2 : rows; }
+    int rows_wg_order = 0;     // workgroup order of the one-map row kernel (kernels_rows.hip: k_fast_rows); 2 for F > 1
+    int rows_group = -1;       // PlanTuning::rows_group
+    bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && F == 1 && fast_rows.ok; }
     // As many maps per workgroup as leaves >= 4 workgroups per resident slot (4 per CU), at most 16:
     // the walk amortises the image-spectrum row, the launch and the store drain, but a grid
     // that no longer fills the chip loses more than that.
@@ -68,10 +69,8 @@ struct Geometry {
         const long g = groups * nmaps / ((long)num_cus * 16);
         return (int)std::max<long>(1, std::min<long>(16, std::min<long>(g, nmaps)));
     }
-    bool rows_persistent = false; // persistent variant of the fast single-row kernel (measured slower: kept for A/B)
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
-        if (y_pre()) return (size_t)(fft_w / 8) * M * 8;
         return y_tiled() ? (size_t)(fft_w / y_tile_w) * tile_rows() * y_tile_w : (size_t)rows * y_pitch;
     }
     size_t map_elems() const { return (size_t)fft_h * fft_w; }
@@ -83,32 +82,28 @@ struct Tables {
     std::vector<PairEntry> pairs;
     FastRowsTables fr;  // only if Geometry::fast_rows.ok
     FastColsTables fcl; // only if Geometry::fast_cols.ok
-    FastColsWideTables fcw; // only if Geometry::fast_colw.ok
 };
 
 // returns false if the sizes are invalid / unsupported
-inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw, int path_mode = 2) {
+inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_kh, int max_kw, const PlanTuning& tune = PlanTuning()) {
+    const int path_mode = (tune.path_mode < 0 || tune.path_mode > 2) ? 2 : tune.path_mode;
     const bool allow_fast = path_mode > 0;
     g.path_mode = path_mode;
-    fast_rows_hook() = allow_fast ? &fast_rows_length : nullptr;   // the planner prefers lengths with fast kernels
-    fast_cols_hook() = allow_fast ? &fast_cols_length : nullptr;
-    if (const char* e = getenv("FFTCONV_TILE_W")) g.y_tile_w = (atoi(e) == 8) ? 8 : 16;        // A/B runs only
-    if (const char* e = getenv("FFTCONV_ROW_ORDER")) g.y_row_order = atoi(e);
-    if (const char* e = getenv("FFTCONV_ROWS_PERSIST")) g.rows_persistent = atoi(e) != 0;
-    if (const char* e = getenv("FFTCONV_ROWS_ORDER")) g.rows_wg_order = atoi(e);
-    if (const char* e = getenv("FFTCONV_ROWS_GROUP")) g.rows_group = atoi(e);
-    if (const char* e = getenv("FFTCONV_PAIR_ROWS")) g.pair_rows_on = atoi(e) != 0;
+    g.rows_group = tune.rows_group;
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
     // F > 1 (plain row kernel, one map per workgroup): every (map, feature) re-reads an image-spectrum
     // row, F times the traffic of F = 1; the XCD-aware order with the kernel index fastest lets the
     // workgroups of one row take it from their XCD's L2 (cfg3 with F = 4: 92 -> 79 us per map)
-    if (F > 1 && !getenv("FFTCONV_ROWS_ORDER")) g.rows_wg_order = 2;
+    g.rows_wg_order = F > 1 ? 2 : 0;
     g.fft_h = fft_size16(H + max_kh - 1);
     g.fft_w = fft_size16(W + max_kw - 1);
-    g.Lh = choose_length(H + max_kh - 1, true, g.fft_h);
-    g.Lw = choose_length(W + max_kw - 1, false, g.fft_w);
+    LengthPrefs prefs;   // the planner prefers lengths with specialised kernels (able to take max_kw)
+    if (allow_fast) { prefs.fast_rows = &fast_rows_length; prefs.fast_cols = &fast_cols_length; prefs.max_kw = max_kw; }
+    g.Lh = choose_length(H + max_kh - 1, true, g.fft_h, prefs);
+    g.Lw = choose_length(W + max_kw - 1, false, g.fft_w, prefs);
     if (g.Lh < 2 || g.Lw < 1) return false;
+    if (tune.max_transform > 0 && (g.Lh > tune.max_transform || g.Lw > tune.max_transform)) return false;
     g.M = g.Lh / 2;
     g.rows = g.M + 1;
     g.s_pitch = round_up(g.Lw, 8);
@@ -127,22 +122,12 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     g.fast_rows = allow_fast ? fast_rows_lookup(g.Lw, max_kw) : FastRowsInfo();
     if (g.fast_rows.ok) t.fr = make_fast_rows_tables(g.fast_rows, t.pw);
     // the fast output kernel crops (window <= transform) but does not zero-fill (window > transform)
-    int prefer_T = 0;
-    if (const char* e = getenv("FFTCONV_COLS_T")) prefer_T = atoi(e);                          // A/B runs only
-    g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M, prefer_T) : FastColsInfo();
+    g.fast_cols = (allow_fast && g.Lh >= g.fft_h && g.Lw >= g.fft_w) ? fast_cols_lookup(g.M) : FastColsInfo();
     if (g.fast_cols.ok && (g.fft_w % g.fast_cols.T != 0)) g.fast_cols = FastColsInfo();
-    bool fwd_on = true;
-    if (const char* e = getenv("FFTCONV_FAST_FWD")) fwd_on = atoi(e) != 0;                     // A/B runs only
-    g.fast_fwd = g.fast_cols.ok && fwd_on;
+    g.fast_fwd = g.fast_cols.ok;
     // the plan whose digit-reversed order the spectrum rows are produced in
     Plan1D producer = g.fast_fwd ? make_plan1d_seq(g.M, {g.fast_cols.R1, g.fast_cols.R2, g.fast_cols.R3}) : t.pm;
-    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, producer, g.y_pitch, g.y_row_order);
-    // 16-column output kernel: correct but over the 168-VGPR budget of 3 waves/SIMD (spills: 86 us
-    // per map instead of 35), so off unless asked for; see DESIGN.md
-    bool wide_on = false;
-    if (const char* e = getenv("FFTCONV_COLS_WIDE")) wide_on = atoi(e) != 0;
-    g.fast_colw = (wide_on && g.fast_cols.ok) ? fast_cols_wide_lookup(g.M) : FastColsWideInfo();
-    if (g.fast_colw.ok) t.fcw = make_fast_cols_wide_tables(g.fast_colw, producer);
+    if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, producer, g.y_pitch);
     return true;
 }
 
@@ -158,17 +143,8 @@ struct DeviceTables {
     const c32* fc_tw2 = nullptr;
     const PairEntry* fc_pairs = nullptr;
     const int* fc_rowoff = nullptr;
-    const int* fc_tile_row_of = nullptr;
-    const RowPair* fc_row_pairs = nullptr;
-    const int* fc_lpos = nullptr;
-    const int* fc_tile_lpos = nullptr;
     const int* fc_pair_row_of = nullptr;
-    const int* fc_pair_row_seq = nullptr;
-    // 16-column output kernel
-    const c32* cw_tw3 = nullptr; const c32* cw_twA = nullptr; const c32* cw_twF = nullptr;
-    const c32* cw_wh = nullptr; const c32* cw_wl = nullptr;
-    const unsigned* cw_ppA = nullptr; const unsigned* cw_ppB = nullptr;
-    const int* cw_tile_row_of = nullptr;
+    unsigned long long* timeline = nullptr;   // FC_ROWS_TIMELINE / FC_COLS_TIMELINE builds only (plan option "timeline_ptr")
 };
 
 // image columns: planes = F, columns = W, valid samples = H
@@ -223,19 +199,9 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.S = S; a.s_feat_stride = (size_t)g.rows * g.s_pitch; a.s_pitch = g.s_pitch;
     a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch; a.wout = g.wout;
     a.F = g.F; a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
-    a.y_row_of = g.y_tiled() ? (g.use_wide() ? d.cw_tile_row_of : (g.y_pair_rows() ? d.fc_pair_row_of : d.fc_tile_row_of)) : nullptr;
-    a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
-    a.row_seq = (g.rows_persistent && g.y_pair_rows()) ? d.fc_pair_row_seq : nullptr;
-    if (const char* e = getenv("FFTCONV_ROWS_TIMELINE_PTR")) a.row_seq = reinterpret_cast<const int*>(strtoull(e, nullptr, 0));   // FC_ROWS_TIMELINE builds (the multi-map kernel does not use row_seq)
-    return a;
-}
-
-// paired rows -> precombined tiled intermediate (g.y_pre()); launch with M/2 + 1 workgroups per kernel
-inline FastRowsPairArgs fast_rows_pair_args(const Geometry& g, const DeviceTables& d, const c32* A, int kw, const c32* S, c32* Y) {
-    FastRowsPairArgs a{};
-    a.r = fast_rows_args(g, d, A, kw, S, Y);
-    a.r.y_row_of = nullptr; a.r.y_tile_elems = g.M * 8;
-    a.pairs = d.fc_row_pairs;
+    a.y_row_of = g.y_tiled() ? d.fc_pair_row_of : nullptr;
+    a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift;
+    a.timeline = d.timeline;
     return a;
 }
 
@@ -247,23 +213,8 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
     a.tiles_per_kernel = g.fft_w / g.fast_cols.T; a.ntiles = a.tiles_per_kernel * nk;
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
-    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift();
-    a.y_pair_rows = g.y_pair_rows() ? 1 : 0;
-    a.y_precombined = g.y_pre() ? 1 : 0; a.lpos = g.y_pre() ? d.fc_lpos : d.fc_tile_lpos;
-    if (g.y_pre()) a.y_tile_elems = g.M * 8;
-    a.timeline = nullptr;
-    if (const char* e = getenv("FFTCONV_COLS_TIMELINE_PTR")) a.timeline = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));   // FC_COLS_TIMELINE builds
-    return a;
-}
-
-inline FastColsWideArgs fast_cols_wide_args(const Geometry& g, const DeviceTables& d, const c32* Y, float* out,
-                                            size_t out_kernel_stride, int nk) {
-    FastColsWideArgs a{};
-    a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel();
-    a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
-    a.tiles_per_kernel = g.fft_w / 16; a.ntiles = a.tiles_per_kernel * nk;
-    a.tw3 = d.cw_tw3; a.twA = d.cw_twA; a.twF = d.cw_twF; a.wh = d.cw_wh; a.wl = d.cw_wl;
-    a.ppA = d.cw_ppA; a.ppB = d.cw_ppB;
+    a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift;
+    a.timeline = d.timeline;
     return a;
 }
 

@@ -6,8 +6,9 @@
 // src/cudaConvolutionFFT.cu:103-112): the OUTPUT window is FFT_X = ceil16(DATA_X + MAXK_X - 1).
 // The INTERNAL transform length L_X only has to satisfy L_X >= DATA_X + MAXK_X - 1 (linear
 // convolution support); it is chosen as the cheapest length that factors into the supported
-// radices.  When L_X == FFT_X (true for every BASELINE config) the engine computes exactly the
-// reference's circular convolution modulo FFT_X.
+// radices, preferring lengths that have specialised kernels.  When L_X == FFT_X (cfg1 / cfg3 / cfg5:
+// 288, 4224, 2112) the engine computes exactly the reference's circular convolution modulo FFT_X;
+// cfg2 (window 1088) and cfg4 (window 4160) run on 1152 / 4224 and crop.
 #pragma once
 #include <cmath>
 #include <vector>
@@ -69,37 +70,41 @@ inline std::vector<int> factorize(int L) {
 inline bool length_supported(int L) { return L == 1 || !factorize(L).empty(); }
 
 // Lengths for which a specialised kernel exists (fast_paths.hpp) run ~2.5x faster than the generic
-// kernels; the hooks are set by fast_paths.hpp so that this header stays independent of it.
-using LengthPredicate = bool (*)(int);
-inline LengthPredicate& fast_rows_hook() { static LengthPredicate h = nullptr; return h; }
-inline LengthPredicate& fast_cols_hook() { static LengthPredicate h = nullptr; return h; }
+// kernels.  The predicates come from fast_paths.hpp through this struct so that this header stays
+// independent of it (nullptr: no preference); `ctx` is the widest kernel the row kernel must take.
+using LengthPredicate = bool (*)(int L, int ctx);
+struct LengthPrefs {
+    LengthPredicate fast_rows = nullptr;   // w direction (complex transform of length L)
+    LengthPredicate fast_cols = nullptr;   // h direction (complex transform of length L / 2)
+    int max_kw = 1;
+};
 
-inline double length_cost(int L, bool real_half) {
+inline double length_cost(int L, bool real_half, const LengthPrefs& prefs) {
     // real_half: the transform actually run is complex of length L/2 (+ pair pass)
     int Lc = real_half ? L / 2 : L;
     std::vector<int> r = factorize(Lc);
     if (Lc != 1 && r.empty()) return 1e30;
     double c = 40.0 + (real_half ? 10.0 : 0.0);
     for (int x : r) c += radix_cost(x) * (real_half ? 0.5 : 1.0);
-    if (real_half ? (fast_cols_hook() && fast_cols_hook()(Lc)) : (fast_rows_hook() && fast_rows_hook()(L))) c *= 0.45;
+    if (real_half ? (prefs.fast_cols && prefs.fast_cols(Lc, 0)) : (prefs.fast_rows && prefs.fast_rows(L, prefs.max_kw))) c *= 0.45;
     return c * (double)L;
 }
 
 // Cheapest supported length >= need (even if real_half).  `exact` (>= need, e.g. the ceil16
 // window) wins ties and is preferred when within 10 % of the optimum, so that the common case
 // reproduces the reference's circular-convolution modulus exactly.
-inline int choose_length(int need, bool real_half, int exact) {
+inline int choose_length(int need, bool real_half, int exact, const LengthPrefs& prefs = LengthPrefs()) {
     if (need < 1) need = 1;
     int best = -1;
     double bc = 1e30;
     int hi = 2 * need + 32;
     for (int L = need; L <= hi; L++) {
         if (real_half && (L & 1)) continue;
-        double c = length_cost(L, real_half);
+        double c = length_cost(L, real_half, prefs);
         if (c < bc) { bc = c; best = L; }
     }
     if (exact >= need && (!real_half || !(exact & 1))) {
-        double c = length_cost(exact, real_half);
+        double c = length_cost(exact, real_half, prefs);
         if (c <= bc * 1.10) best = exact;
     }
     return best;

@@ -1,16 +1,27 @@
-"""Filter sharding across the GPUs of one node (one process per GPU, torch.distributed).
+"""The N > 1 steps of the hot path, one process per GPU (torch.distributed): THE implementation,
+used by bench.py, by the world_size-2 gloo CPU test (host emulator as engine) and by the -m gpu
+test (two processes on one GPU, HIP plans as engines).
 
-The reference's intent (src/cudaConvFFTDataStreams.cu:273-328,338-447): one image spectrum,
-kernels dealt out over the devices, the spectrum copied from GPU 0 to the others
-(cudaMemcpyPeerAsync, :279-289).  Here: contiguous filter blocks per rank and ONE broadcast of
-the spectrum buffer (RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" in the
-CPU tests).  Outputs stay sharded -- no reduce or gather is needed, maps are independent.
+Filter sharding (BASELINE configs[3]; the reference's intent, src/cudaConvFFTDataStreams.cu:
+273-328 per-GPU plans, :279-289 spectrum copy GPU 0 -> GPU g, :338-447 kernels dealt over the
+plans, :452-468 barrier): rank r owns a contiguous block of the filters, rank `src` transforms
+the image, ONE broadcast of the spectrum buffer (RCCL over xGMI through torch.distributed's
+"nccl" backend; "gloo" in the tests) is the only collective; maps stay sharded.
 
-The functions are written against a small engine protocol so the same orchestration drives the
-HIP plan on GPUs (bench.py) and the host emulator in the world_size-2 gloo tests:
-    engine.compute_spectrum(spec_tensor)       rank 0: image -> spectrum, in place in spec_tensor
-    engine.convolve(spec_tensor, first, count) this rank's filters [first, first+count)
+Image streaming (BASELINE configs[4]; async H2D / D2H intent of src/cudaConvFFTDataStreams.cu:
+368-371,429-430): every rank convolves its own images with all kernels, the H2D copy of image
+i + 1 on a side stream behind the compute of image i; no collective.
+
+Both are written against a small engine protocol so the same orchestration drives HIP plans and
+the host emulator:
+    engine.sync                              stream / event helper (NullSync on the CPU)
+    engine.new_spectrum()                    a buffer the communication backend can broadcast
+    engine.compute_spectrum(spec, image)     image -> spectrum, in place in `spec` (current stream)
+    engine.prepare_kernels(first, count)     optional image-independent part of convolve
+    engine.convolve(spec, first, count)      this rank's filters [first, first + count) -> maps
+    engine.new_image_buffer() / engine.upload(buf, host_image)      (image streaming only)
 """
+import contextlib
 
 
 def filter_shard(n_filters, rank, world):
@@ -24,12 +35,217 @@ def filter_shard(n_filters, rank, world):
     return first, count
 
 
-def sharded_convolution(engine, spec, n_filters, rank, world, dist=None, src=0):
-    """One step of the multi-GPU hot path.  `spec` is this rank's spectrum buffer (a tensor the
-    communication backend can broadcast).  Returns whatever engine.convolve returns for the shard."""
-    if rank == src:
-        engine.compute_spectrum(spec)
-    if world > 1:
-        dist.broadcast(spec, src=src)      # the single collective of the path
-    first, count = filter_shard(n_filters, rank, world)
-    return engine.convolve(spec, first, count)
+def image_shard(n_images, rank, world):
+    """Contiguous block of images owned by `rank` (image streaming): (first, count)."""
+    return filter_shard(n_images, rank, world)
+
+
+class NullSync:
+    """Stream / event helper of an engine that computes synchronously on the host."""
+
+    def event(self):
+        return None
+
+    def side(self):
+        return contextlib.nullcontext()
+
+    def record(self, ev, side=False):
+        pass
+
+    def wait(self, ev, side=False):
+        pass
+
+
+class TorchStreamSync:
+    """Two HIP streams of one device through torch: `main` (the plan's stream, where the maps are
+    computed) and `side` (image transform + broadcast of the next step, or H2D copies)."""
+
+    def __init__(self, torch, device, main=None):
+        self.torch = torch
+        self.main = main if main is not None else torch.cuda.current_stream(device)
+        self.side_stream = torch.cuda.Stream(device)
+
+    def event(self):
+        return self.torch.cuda.Event()
+
+    def side(self):
+        return self.torch.cuda.stream(self.side_stream)
+
+    def record(self, ev, side=False):
+        ev.record(self.side_stream if side else self.main)
+
+    def wait(self, ev, side=False):
+        # an event that was never recorded is complete: the first use of every buffer does not wait
+        (self.side_stream if side else self.main).wait_event(ev)
+
+
+class FilterShardedConvolver:
+    """One image against n_filters kernels sharded over the ranks.
+
+        submit(image)   rank src: image -> spectrum buffer b; all ranks: broadcast of buffer b
+                        (side stream: runs beside the maps of the previous step)
+        convolve()      this rank's filter block against the oldest submitted spectrum
+        step(image)     submit + convolve
+
+    `depth` spectrum buffers: with depth = 2 the caller may submit step k + 1 before it convolves
+    step k, which takes the image transform and the broadcast off the critical path of every step
+    but the first.  A buffer is overwritten only after the convolve that read it (events)."""
+
+    def __init__(self, engine, dist, rank, world, n_filters, src=0, depth=2, always_collective=False):
+        self.engine, self.dist, self.rank, self.world, self.src = engine, dist, rank, world, src
+        self.first, self.count = filter_shard(n_filters, rank, world)
+        self.depth = max(1, int(depth))
+        self.collective = world > 1 or always_collective
+        self.spec = [engine.new_spectrum() for _ in range(self.depth)]
+        s = engine.sync
+        self.ready = [s.event() for _ in range(self.depth)]      # spectrum b complete on this rank
+        self.consumed = [s.event() for _ in range(self.depth)]   # the convolve that read buffer b is done
+        self.n_sub = self.n_conv = 0
+
+    def submit(self, image=None):
+        if self.n_sub - self.n_conv >= self.depth:
+            raise RuntimeError("submit: all %d spectrum buffers hold steps that were not convolved yet" % self.depth)
+        b = self.n_sub % self.depth
+        s = self.engine.sync
+        with s.side():
+            s.wait(self.consumed[b], side=True)
+            if self.rank == self.src:
+                self.engine.compute_spectrum(self.spec[b], image)
+            if self.collective:
+                # the single collective of the path; issued from the side stream: the backend orders
+                # it behind the transform above and wait() orders the side stream behind it
+                work = self.dist.broadcast(self.spec[b], src=self.src, async_op=True)
+                work.wait()
+            s.record(self.ready[b], side=True)
+        self.n_sub += 1
+
+    def convolve(self):
+        if self.n_conv >= self.n_sub:
+            raise RuntimeError("convolve: nothing submitted")
+        b = self.n_conv % self.depth
+        s = self.engine.sync
+        prep = getattr(self.engine, "prepare_kernels", None)
+        if prep is not None:
+            prep(self.first, self.count)          # does not need the image: overlaps the broadcast
+        s.wait(self.ready[b])
+        res = self.engine.convolve(self.spec[b], self.first, self.count)
+        s.record(self.consumed[b])
+        self.n_conv += 1
+        return res
+
+    def step(self, image=None):
+        self.submit(image)
+        return self.convolve()
+
+    def run(self, images, on_result=None):
+        """Convolves a sequence of images (each against this rank's filter block), the image
+        transform + broadcast of image k + 1 overlapped with the maps of image k.  On ranks other
+        than src the entries of `images` are ignored (None is fine)."""
+        images = list(images)
+        last = None
+        if images:
+            self.submit(images[0])
+        for k in range(len(images)):
+            if k + 1 < len(images) and self.depth > 1:
+                self.submit(images[k + 1])
+            last = self.convolve()
+            if on_result is not None:
+                on_result(k, last)
+            if k + 1 < len(images) and self.depth == 1:
+                self.submit(images[k + 1])
+        return last
+
+
+class ImageStreamedConvolver:
+    """This rank's images against all kernels, H2D of image i + 1 (side stream, two device
+    buffers) behind the compute of image i.  No collective: ranks are independent."""
+
+    def __init__(self, engine, n_filters):
+        self.engine, self.n_filters = engine, n_filters
+        self.spec = engine.new_spectrum()
+        self.buf = [engine.new_image_buffer() for _ in range(2)]
+        s = engine.sync
+        self.copied = [s.event() for _ in range(2)]
+        self.consumed = [s.event() for _ in range(2)]   # the image transform that read buffer b is done
+
+    def _upload(self, b, host_image):
+        s = self.engine.sync
+        with s.side():
+            s.wait(self.consumed[b], side=True)     # also across run() calls: the buffer's last reader
+            self.engine.upload(self.buf[b], host_image)
+            s.record(self.copied[b], side=True)
+
+    def run(self, host_images, on_result=None):
+        host_images = list(host_images)
+        s = self.engine.sync
+        last = None
+        if host_images:
+            self._upload(0, host_images[0])
+        for i in range(len(host_images)):
+            b = i & 1
+            if i + 1 < len(host_images):
+                self._upload(1 - b, host_images[i + 1])   # next image's H2D while this one is convolved
+            s.wait(self.copied[b])
+            self.engine.compute_spectrum(self.spec, self.buf[b])
+            s.record(self.consumed[b])
+            last = self.engine.convolve(self.spec, 0, self.n_filters)
+            if on_result is not None:
+                on_result(i, last)
+        return last
+
+
+class HipPlanEngine:
+    """Engine over one fftconv Plan (HIP kernels) with device-resident kernels and maps, through
+    torch tensors for memory and streams.  `kernels` is this rank's block, packed [n][F][kw][kh];
+    convolve() returns the device tensor [n][FFT_W][FFT_H] it fills (reused by every call)."""
+
+    def __init__(self, torch, fc, plan, device, kernels, kh, kw, first=0, main_stream=None, overlap=True):
+        self.torch, self.fc, self.plan, self.device = torch, fc, plan, device
+        self.kernels, self.kh, self.kw, self.first = kernels, kh, kw, first
+        self.count = int(kernels.shape[0])
+        # the stream the plan is bound to (where the maps are computed)
+        self.main_stream = main_stream if main_stream is not None else torch.cuda.current_stream(device)
+        # overlap: a side stream for the next step's image transform / broadcast / H2D copies;
+        # without it everything is queued on the plan's stream in program order (no events needed)
+        self.sync = TorchStreamSync(torch, device, self.main_stream) if overlap else NullSync()
+        info = plan.info
+        self.out = torch.empty((max(1, self.count), info.fft_w, info.fft_h), dtype=torch.float32, device=device)
+        self._keep = None
+
+    def new_spectrum(self):
+        return self.torch.empty(self.plan.info.spectrum_bytes, dtype=self.torch.uint8, device=self.device)
+
+    def new_image_buffer(self):
+        i = self.plan.info
+        return self.torch.empty((i.feature_dim, i.data_w, i.data_h), dtype=self.torch.float32, device=self.device)
+
+    def upload(self, buf, host_image):
+        buf.copy_(host_image, non_blocking=True)    # pinned host tensor [F][W][H]: asynchronous H2D
+
+    def compute_spectrum(self, spec, image):
+        """image: device tensor [F][W][H].  Runs on torch's CURRENT stream (the convolver makes the
+        side stream current for it): the plan is re-bound for the call."""
+        cur = self.torch.cuda.current_stream(self.device)
+        self.plan.use_spectrum_buffer(spec.data_ptr(), spec.numel())
+        rebind = cur.cuda_stream != self.main_stream.cuda_stream
+        if rebind:
+            self.plan.set_stream(cur.cuda_stream)
+        try:
+            self.plan.set_image_device(image.data_ptr())
+        finally:
+            if rebind:
+                self.plan.set_stream(self.main_stream.cuda_stream)
+        self._keep = image
+
+    def prepare_kernels(self, first, count):
+        assert (first, count) == (self.first, self.count)
+        if count:
+            self.plan.prepare_kernels_packed_device(count, self.kernels.data_ptr(), self.kh, self.kw)
+
+    def convolve(self, spec, first, count):
+        assert (first, count) == (self.first, self.count), "engine was built for another filter block"
+        self.plan.use_spectrum_buffer(spec.data_ptr(), spec.numel())
+        self.plan.mark_spectrum_valid()
+        if count:
+            self.plan.convolve_packed_device(count, self.kernels.data_ptr(), self.kh, self.kw, self.out.data_ptr())
+        return self.out

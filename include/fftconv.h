@@ -93,6 +93,16 @@ int fftconv_convolution_fft(const float *data, int data_h, int data_w, int featu
                             const double *thread_size, int n_thread_size,
                             int gpu_id,
                             float *const *out, int *fft_h, int *fft_w);
+/* The same with plan options (forward-declared below; NULL = defaults). */
+struct fftconv_plan_options;
+int fftconv_convolution_fft_ex(const float *data, int data_h, int data_w, int feature_dim,
+                               int max_kernel_h, int max_kernel_w,
+                               int n_kernel, const float *const *kernels,
+                               const int *kernel_h, const int *kernel_w, const int *kernel_f,
+                               const double *thread_size, int n_thread_size,
+                               int gpu_id,
+                               float *const *out, int *fft_h, int *fft_w,
+                               const struct fftconv_plan_options *options);
 
 /* ------------------------------------------------------------------------------------------
  * Plan API: the state the reference keeps inside one mexFunction call (cuFFT plans
@@ -124,6 +134,27 @@ typedef struct fftconv_plan_info {
 /* hip_stream: hipStream_t to run on (NULL = the device's default stream). */
 int fftconv_plan_create(fftconv_plan **plan, int data_h, int data_w, int feature_dim,
                         int max_kernel_h, int max_kernel_w, int gpu_id, void *hip_stream);
+
+/* Choices fixed at plan creation.  Zero-initialise, set struct_size = sizeof(fftconv_plan_options),
+ * then the fields wanted; NULL options = all defaults.  The library reads no environment
+ * variables: everything that steers it goes through this struct or fftconv_plan_set_option. */
+typedef struct fftconv_plan_options {
+    size_t struct_size;
+    int kernel_path;    /* 0 (default): specialised kernels where the transform lengths have them, tiled
+                         *    intermediate; 1: generic kernels only (any supported length; the cross-check of
+                         *    the specialised path); 2: specialised kernels with a row-major intermediate */
+    int rows_group;     /* maps one workgroup of the spectral-row kernel walks with its image-spectrum row in
+                         *    registers (F = 1): 0 (default) chosen per launch, 1 one map per workgroup, n > 1 fixed */
+    int max_transform;  /* > 0: largest transform length a plan may use; creation fails with
+                         *    FFTCONV_ERR_UNSUPPORTED_SIZE beyond it and the one-shot entry goes block-wise
+                         *    (overlap-add) with blocks of at most this size */
+} fftconv_plan_options;
+int fftconv_plan_create_ex(fftconv_plan **plan, int data_h, int data_w, int feature_dim,
+                           int max_kernel_h, int max_kernel_w, int gpu_id, void *hip_stream,
+                           const fftconv_plan_options *options);
+/* 1 if `plan` is a live plan of this library (created and not yet destroyed), else 0.  The MEX
+ * gateways check the uint64 handles MATLAB hands back with it before dereferencing them. */
+int fftconv_plan_is_live(const fftconv_plan *plan);
 int fftconv_plan_destroy(fftconv_plan *plan);
 int fftconv_plan_get_info(const fftconv_plan *plan, fftconv_plan_info *info);
 
@@ -180,6 +211,7 @@ int fftconv_plan_set_stream(fftconv_plan *plan, void *hip_stream);
 int fftconv_plan_synchronize(fftconv_plan *plan);
 
 /* Options: "batch_maps" (kernels per spectral/output launch, 0 = auto),
+ *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
  *          "profile" (1: time every kernel launch with HIP events on the plan's stream),
  *          "host_stream" (how maps reach HOST output buffers -- the reference's blocking
  *             cudaMemcpy per map, src/cudaConvolutionFFT.cu:284-286: 0 = blocking copies after each
@@ -218,6 +250,47 @@ int fftconv_fft_data(const float *data, int data_h, int data_w, int feature_dim,
 int fftconv_conv_fft_data(fftconv_plan *fft_data, int n_kernel, const float *const *kernels,
                           const int *kernel_h, const int *kernel_w, const int *kernel_f,
                           const double *thread_size, int n_thread_size, float *const *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Several GPUs from one process: the reference's multi-GPU / multi-stream sketch
+ * (src/cudaConvFFTDataStreams.cu -- one ConvPlan per (GPU, stream) with private scratch :273-328,
+ * the image spectrum copied from GPU 0 to GPU g with cudaMemcpyPeerAsync :279-289, kernels dealt
+ * over the plans :338-447, a synchronisation barrier at the end :452-468; it never built or ran).
+ * Here: one plan and one stream per listed device, the image transformed once on devices[0], its
+ * spectrum copied to every other device over xGMI (hipMemcpyPeerAsync, each copy on the
+ * destination's stream so that the links work in parallel), the kernels dealt in CONTIGUOUS
+ * blocks (device g of n takes kernels [g*N/n, (g+1)*N/n), sizes differing by at most one), one
+ * host thread per device while a call runs, everything complete on return.  The same device may
+ * be listed more than once (two plans on one GPU: the reference's N_BATCH_PER_GPU = 2).
+ * With one process per GPU (torch.distributed / RCCL) use the plan API and broadcast the
+ * spectrum buffer instead: INTEGRATION.md.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fftconv_multi fftconv_multi;
+int fftconv_multi_create(fftconv_multi **multi, int data_h, int data_w, int feature_dim,
+                         int max_kernel_h, int max_kernel_w, const int *devices, int n_devices,
+                         const fftconv_plan_options *options);
+int fftconv_multi_destroy(fftconv_multi *multi);
+/* padData + cufftExecR2C of the image on devices[0] (src/cudaConvolutionFFT.cu:144-169), then the
+ * peer copies.  location FFTCONV_HOST, or FFTCONV_DEVICE for memory of devices[0]. */
+int fftconv_multi_set_image(fftconv_multi *multi, const float *data, int location);
+/* The per-kernel loop over all devices.  FFTCONV_HOST kernels / outputs are plain host arrays;
+ * FFTCONV_DEVICE pointers must live on the device that owns the kernel (fftconv_multi_shard). */
+int fftconv_multi_convolve(fftconv_multi *multi, int n_kernel, const float *const *kernels,
+                           const int *kernel_h, const int *kernel_w, int kernel_location,
+                           float *const *out, int out_location);
+/* Block of kernels device `index` (position in devices[]) owns among n_kernel. */
+int fftconv_multi_shard(const fftconv_multi *multi, int n_kernel, int index, int *first, int *count);
+/* Number of plans, and the plan / device id at a position (for fftconv_plan_get_info, options,
+ * or packed device-resident calls on one device; the plan stays owned by the multi handle). */
+int fftconv_multi_size(const fftconv_multi *multi);
+int fftconv_multi_plan(fftconv_multi *multi, int index, fftconv_plan **plan, int *device);
+/* One-shot form: fftconv_convolution_fft with a list of devices instead of one gpu_id. */
+int fftconv_convolution_fft_multi(const float *data, int data_h, int data_w, int feature_dim,
+                                  int max_kernel_h, int max_kernel_w,
+                                  int n_kernel, const float *const *kernels,
+                                  const int *kernel_h, const int *kernel_w, const int *kernel_f,
+                                  const int *devices, int n_devices,
+                                  float *const *out, int *fft_h, int *fft_w);
 
 #ifdef __cplusplus
 }

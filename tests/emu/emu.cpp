@@ -50,7 +50,6 @@ struct EmuFastRows {
     const FastRowsArgs& a;
     c32* lds;
     int rows;
-    bool persist;
     int group = 0;   // > 1: multi-map body; the emulator holds one kernel at a time, so the walk
                      // over `group` maps is emulated with the same kernel (strides 0): the loop,
                      // the prefetch slot and the LDS reuse are exercised, the indexing is not
@@ -68,23 +67,6 @@ struct EmuFastRows {
             }
             return;
         }
-        if constexpr (Cfg::RPW == 1)
-        if (persist) {   // 5 persistent workgroups share the rows (uneven split on purpose)
-            const int nwg = 5, total = rows;
-            for (int wg = 0; wg < nwg; wg++) {
-                const int base = total / nwg, rem = total - base * nwg;
-                const int item0 = wg * base + (wg < rem ? wg : rem), item1 = item0 + base + (wg < rem ? 1 : 0);
-                for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-                if (a.F > 1) {
-                    HostPhaseCtx<RowState<Cfg, true>> ctx(Cfg::NT);
-                    fast_rows_persist_body<Cfg, NZ2, true>(ctx, lds, a, rows, item0, item1);
-                } else {
-                    HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
-                    fast_rows_persist_body<Cfg, NZ2, false>(ctx, lds, a, rows, item0, item1);
-                }
-            }
-            return;
-        }
         for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
             // poison the LDS image so that reads of never-written cells show up
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
@@ -94,25 +76,6 @@ struct EmuFastRows {
             } else {
                 HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
                 fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, grp, 0, rows);
-            }
-        }
-    }
-};
-
-struct EmuFastRowsPair {
-    const FastRowsPairArgs& a;
-    c32* lds;
-    int pairs;
-    template <class Cfg, int NZ2>
-    void go() {
-        for (int u = 0; u < pairs; u++) {
-            for (int i = 0; i < 2 * (Cfg::L + 16) + Cfg::T2N + Cfg::m1; i++) lds[i] = mk(1e30f, -1e30f);
-            if (a.r.F > 1) {
-                HostPhaseCtx<RowPairState<Cfg, true>> ctx(2 * Cfg::NT);
-                fast_rows_pair_body<Cfg, NZ2, true>(ctx, lds, a, u, 0);
-            } else {
-                HostPhaseCtx<RowPairState<Cfg, false>> ctx(2 * Cfg::NT);
-                fast_rows_pair_body<Cfg, NZ2, false>(ctx, lds, a, u, 0);
             }
         }
     }
@@ -132,20 +95,6 @@ struct EmuFastColsFwd {
     }
 };
 
-struct EmuFastColsWide {
-    const FastColsWideArgs& a;
-    c32* lds;
-    int nwg;
-    template <class Cfg>
-    void go() {
-        for (int wg = 0; wg < nwg; wg++) {
-            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            HostPhaseCtx<ColWideState<Cfg>> ctx(Cfg::NT);
-            fast_cols_wide_body<Cfg>(ctx, lds, a, wg, nwg);
-        }
-    }
-};
-
 struct EmuFastCols {
     const FastColsArgs& a;
     c32* lds;
@@ -154,21 +103,18 @@ struct EmuFastCols {
     void go() {
         for (int wg = 0; wg < nwg; wg++) {
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            if (a.y_tiled && a.y_pair_rows && !a.y_precombined) {
+            if (a.y_tiled) {
                 HostPhaseCtx<ColPairState<Cfg>> pctx(Cfg::NT);
-                fast_cols_body<Cfg, 3>(pctx, lds, a, wg, nwg);
+                fast_cols_body<Cfg, true>(pctx, lds, a, wg, nwg);
                 continue;
             }
             HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
-            if (a.y_precombined) {
-                if constexpr (Cfg::T == 8) fast_cols_body<Cfg, 2>(ctx, lds, a, wg, nwg);
-            } else if (a.y_tiled) fast_cols_body<Cfg, 1>(ctx, lds, a, wg, nwg);
-            else fast_cols_body<Cfg, 0>(ctx, lds, a, wg, nwg);
+            fast_cols_body<Cfg, false>(ctx, lds, a, wg, nwg);
         }
     }
 };
 
-int g_allow_fast = 2;   // path mode (pipeline.hpp Geometry::path_mode)
+PlanTuning g_tune;   // path mode / rows group of the emulated plans (pipeline.hpp PlanTuning)
 }  // namespace
 
 extern "C" {
@@ -177,7 +123,7 @@ extern "C" {
 long emu_spectrum_elems(int H, int W, int F, int max_kh, int max_kw) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     return (long)g.spectrum_elems();
 }
 
@@ -185,7 +131,7 @@ long emu_spectrum_elems(int H, int W, int F, int max_kh, int max_kw) {
 int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int max_kw, float* spec_out) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     DeviceTables d;
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
@@ -216,7 +162,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
                           const float* const* kernels, const int* kh, const int* kw, float* const* out) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     DeviceTables d;
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
@@ -242,41 +188,19 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             for (int plane = 0; plane < F; plane++)
                 for (int tile = 0; tile < tiles_for(kw[k], g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ka, tile, plane);
         }
-        if (g.fast_cols.ok) d.fc_tile_row_of = t.fcl.tile_row_of.data();
-        if (g.fast_colw.ok) d.cw_tile_row_of = t.fcw.tile_row_of.data();
-        if (g.fast_cols.ok) {
-            d.fc_row_pairs = t.fcl.row_pairs.data();
-            d.fc_lpos = t.fcl.lpos.data();
-            d.fc_tile_lpos = t.fcl.tile_lpos.data();
-            d.fc_pair_row_of = t.fcl.pair_row_of.data();
-            d.fc_pair_row_seq = t.fcl.pair_row_seq.data();
-        }
-        if (g.y_pre()) {
-            if (kw[k] > g.fast_rows.max_kw) return -4;
-            d.fr_tw1 = t.fr.tw1.data();
-            d.fr_tw2 = t.fr.tw2.data();
-            FastRowsPairArgs fa = fast_rows_pair_args(g, d, A.data(), kw[k], S, Y.data());
-            EmuFastRowsPair run{fa, lds.data(), g.M / 2 + 1};
-            if (!fast_rows_pair_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
-        } else if (g.fast_rows.ok) {
+        if (g.fast_cols.ok) d.fc_pair_row_of = t.fcl.pair_row_of.data();
+        if (g.fast_rows.ok) {
             if (kw[k] > g.fast_rows.max_kw) return -4;
             d.fr_tw1 = t.fr.tw1.data();
             d.fr_tw2 = t.fr.tw2.data();
             FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
-            EmuFastRows run{fa, lds.data(), g.rows, g.rows_persistent, (g.rows_multi_ok() && g.rows_group > 1) ? g.rows_group : 0};
+            EmuFastRows run{fa, lds.data(), g.rows, (g.rows_multi_ok() && g.rows_group > 1) ? g.rows_group : 0};
             if (!fast_rows_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
         } else {
             SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
             for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
         }
-        if (g.use_wide()) {
-            d.cw_tw3 = t.fcw.tw3.data(); d.cw_twA = t.fcw.twA.data(); d.cw_twF = t.fcw.twF.data();
-            d.cw_wh = t.fcw.wh.data(); d.cw_wl = t.fcw.wl.data();
-            d.cw_ppA = t.fcw.ppA.data(); d.cw_ppB = t.fcw.ppB.data();
-            FastColsWideArgs fa = fast_cols_wide_args(g, d, Y.data(), out[k], 0, 1);
-            EmuFastColsWide run{fa, lds.data(), 3};
-            if (!fast_cols_wide_dispatch(g.M, run)) return -7;
-        } else if (g.fast_cols.ok) {
+        if (g.fast_cols.ok) {
             d.fc_tw1 = t.fcl.tw1.data();
             d.fc_tw2 = t.fcl.tw2.data();
             d.fc_pairs = t.fcl.pairs.data();
@@ -299,7 +223,7 @@ int emu_conv_fft(const float* data, int H, int W, int F, int max_kh, int max_kw,
                  int* lh_out, int* lw_out) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     if (lh_out) *lh_out = g.Lh;
     if (lw_out) *lw_out = g.Lw;
     std::vector<float> spec(2 * g.spectrum_elems());
@@ -325,27 +249,27 @@ int emu_fft1d(int L, const float* xin /* 2L floats */, float* xout /* 2L floats 
     return 0;
 }
 
-// path mode: 0 generic kernels only ... 3 (default) everything (pipeline.hpp Geometry::path_mode)
-void emu_allow_fast(int mode) { g_allow_fast = mode; }
+// path mode (0 generic kernels only, 1 specialised + row-major intermediate, 2 default) and maps per
+// workgroup of the multi-map row kernel (-1 auto) of the plans emulated from here on
+void emu_set_tuning(int path_mode, int rows_group) { g_tune.path_mode = path_mode; g_tune.rows_group = rows_group; }
+void emu_allow_fast(int mode) { g_tune.path_mode = mode; }
 // 1 if a plan of these sizes would use the fast spectral-row kernel
 int emu_uses_fast_rows(int H, int W, int F, int max_kh, int max_kw) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     return (g.fast_rows.ok ? 1 : 0) | (g.fast_cols.ok ? 2 : 0);
 }
 
 // the planner alone (no preference for lengths with specialised kernels)
 int emu_choose_length(int need, int real_half, int exact) {
-    fast_rows_hook() = nullptr;
-    fast_cols_hook() = nullptr;
     return choose_length(need, real_half != 0, exact);
 }
 // transform lengths a plan of these sizes would use (path mode as set by emu_allow_fast)
 int emu_plan_lengths(int H, int W, int F, int max_kh, int max_kw, int* lh, int* lw) {
     Geometry g;
     Tables t;
-    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_allow_fast)) return -1;
+    if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     *lh = g.Lh;
     *lw = g.Lw;
     return 0;

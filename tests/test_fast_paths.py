@@ -1,6 +1,6 @@
 """Specialised ("fast") kernels: every path mode / layout variant must give the oracle's answer.
 CPU tier runs the kernel bodies through the host emulator; GPU tier (-m gpu) runs the HIP kernels
-through the C ABI with the same switches (FFTCONV_PATH_MODE etc. are read at plan creation)."""
+through the C ABI with the same choices (fftconv_plan_options at plan creation)."""
 import ctypes
 import os
 import subprocess
@@ -29,10 +29,9 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 # both kernels specialised with the 4-column output tiles (M = 3072 / 4224) and a short
                 # row transform: the pair-adjacent intermediate + merge-while-landing path of those tiles
                 (6000, 250, 1, 60, 31, 2), (8192, 260, 1, 127, 20, 1)]
-VARIANTS = [  # (path_mode, tile_w, row_order, rows_persistent, pair_rows, cols_wide, fast_fwd)
-    (0, 16, 0, 0, 1, 0, 1), (1, 16, 0, 0, 1, 0, 1), (1, 16, 0, 1, 1, 0, 0), (2, 16, 0, 0, 1, 0, 1), (2, 16, 0, 0, 1, 0, 0),
-    (2, 16, 0, 0, 0, 0, 1), (2, 8, 0, 0, 1, 0, 1), (2, 8, 1, 0, 0, 0, 0), (2, 8, 2, 1, 0, 0, 1), (2, 16, 2, 1, 0, 0, 0),
-    (2, 16, 0, 0, 0, 1, 1), (3, 8, 0, 0, 1, 0, 1), (3, 8, 0, 0, 1, 0, 0)]
+# (path_mode, rows_group): path mode 0 generic kernels, 1 specialised kernels + row-major
+# intermediate, 2 (default) specialised kernels + tiled pair-adjacent intermediate; rows_group -1 auto
+VARIANTS = [(0, -1), (1, -1), (2, -1), (2, 0), (2, 3)]
 
 
 _REF_CACHE = {}
@@ -74,69 +73,67 @@ def emu_conv(emu, data, mkh, mkw, kernels):
     return rc, outs
 
 
-def set_variant(monkeypatch, v):
-    mode, tw, ro, pers = v[:4]
-    pair_rows, wide = (v[4], v[5]) if len(v) > 4 else (1, 0)
-    monkeypatch.setenv("FFTCONV_FAST_FWD", str(v[6] if len(v) > 6 else 1))
-    monkeypatch.setenv("FFTCONV_PAIR_ROWS", str(pair_rows))
-    monkeypatch.setenv("FFTCONV_COLS_WIDE", str(wide))
-    monkeypatch.setenv("FFTCONV_TILE_W", str(tw))
-    monkeypatch.setenv("FFTCONV_ROW_ORDER", str(ro))
-    monkeypatch.setenv("FFTCONV_ROWS_PERSIST", str(pers))
-    monkeypatch.setenv("FFTCONV_PATH_MODE", str(mode))
-    monkeypatch.setenv("FFTCONV_ROWS_GROUP", str(v[7] if len(v) > 7 else -1))   # -1: chosen per launch
+def set_variant(emu, v):
+    """emulator: path mode / rows group of the plans emulated from here on"""
+    emu.emu_set_tuning(int(v[0]), int(v[1]) if len(v) > 1 else -1)
+
+
+def plan_options(v):
+    """the same choice as fftconv_plan_options fields for the C ABI"""
+    mode, group = v[0], (v[1] if len(v) > 1 else -1)
+    return {"kernel_path": {2: 0, 0: 1, 1: 2}[mode], "rows_group": 0 if group < 0 else max(1, group)}
+
+
+@pytest.fixture
+def tuned(emu):
+    """sets the emulator's path mode / rows group for one test and restores the defaults after it"""
+    yield lambda v: set_variant(emu, v)
+    emu.emu_set_tuning(2, -1)
 
 
 @pytest.mark.parametrize("shape", ROW_SHAPES + COL_SHAPES)
-@pytest.mark.parametrize("mode", [1, 2, 3])
-def test_emulated_fast_kernels_one_dimension(emu, oracle, monkeypatch, shape, mode):
-    set_variant(monkeypatch, (mode, 16, 0, 0))
-    emu.emu_allow_fast(mode)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_emulated_fast_kernels_one_dimension(emu, oracle, tuned, shape, mode):
+    tuned((mode, -1))
     H, W, F, kh, kw, n = shape
     assert emu.emu_uses_fast_rows(H, W, F, kh, kw) in (1, 2)      # exactly one of the two fast kernels applies
     data, ks = make_inputs(shape, 17)
     rc, got = emu_conv(emu, data, kh, kw, ks)
-    emu.emu_allow_fast(2)
     assert rc == 0
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < 1e-5
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_emulated_fast_kernels_all_variants(emu, oracle, monkeypatch, variant):
+def test_emulated_fast_kernels_all_variants(emu, oracle, tuned, variant):
     """both hot kernels specialised (4224 x 4224 window): every intermediate layout"""
-    set_variant(monkeypatch, variant)
-    emu.emu_allow_fast(variant[0])
+    tuned(variant)
     H, W, F, kh, kw, n = BOTH_SHAPE
     assert emu.emu_uses_fast_rows(H, W, F, kh, kw) == (3 if variant[0] > 0 else 0)
     data, ks = make_inputs(BOTH_SHAPE, 3)
     rc, got = emu_conv(emu, data, kh, kw, ks)
-    emu.emu_allow_fast(2)
     assert rc == 0
     assert util.rel_err(got[0], reference(oracle, BOTH_SHAPE, 3)[0]) < 1e-5
 
 
 @pytest.mark.parametrize("shape", OTHER_SHAPES)
 @pytest.mark.parametrize("mode", [1, 2])
-def test_emulated_fast_kernels_other_configs(emu, oracle, monkeypatch, shape, mode):
-    set_variant(monkeypatch, (mode, 16, 0, 0, 1, 0, mode - 1))   # mode 1: generic forward columns, mode 2: fast
-    emu.emu_allow_fast(mode)
+def test_emulated_fast_kernels_other_configs(emu, oracle, tuned, shape, mode):
+    tuned((mode, -1))
     H, W, F, kh, kw, n = shape
     assert emu.emu_uses_fast_rows(H, W, F, kh, kw) > 0
     data, ks = make_inputs(shape, 29)
     rc, got = emu_conv(emu, data, kh, kw, ks)
-    emu.emu_allow_fast(2)
     assert rc == 0
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < 1e-5
 
 
 @pytest.mark.parametrize("shape", [ROW_SHAPES[0], (256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 1), (2048, 300, 1, 63, 20, 1)])
-def test_emulated_multi_map_row_kernel(emu, oracle, monkeypatch, shape):
+def test_emulated_multi_map_row_kernel(emu, oracle, tuned, shape):
     """fast_rows_multi.hpp (several maps per workgroup): the walk, its prefetch slot and the LDS reuse
     through the emulator (which repeats one kernel; distinct kernels per walk are a GPU test)"""
-    set_variant(monkeypatch, (2, 16, 0, 0, 1, 0, 1, 3))
-    emu.emu_allow_fast(2)
+    tuned((2, 3))
     H, W, F, kh, kw, n = shape
     data, ks = make_inputs(shape, 43)
     rc, got = emu_conv(emu, data, kh, kw, ks)
@@ -145,32 +142,40 @@ def test_emulated_multi_map_row_kernel(emu, oracle, monkeypatch, shape):
         assert util.rel_err(g, r) < 1e-5
 
 
-def test_fast_row_kernel_rejects_too_wide_kernels(emu, monkeypatch):
+def test_fast_row_kernel_rejects_too_wide_kernels(emu):
     # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224); plans for
     # wider MAX_KERNEL_W fall back to the generic kernel at plan time
     assert emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) == 0
+
+
+def test_planner_discounts_only_lengths_whose_row_kernel_takes_max_kw(emu):
+    """the length preference knows MAX_KERNEL_W: 4224 is preferred for 127-wide kernels, but a plan
+    for 600-wide kernels (wider than the fast kernel's 528) is not steered to a length it cannot use fast"""
+    lh, lw = ctypes.c_int(0), ctypes.c_int(0)
+    assert emu.emu_plan_lengths(12, 4096, 1, 3, 127, ctypes.byref(lh), ctypes.byref(lw)) == 0
+    assert lw.value == 4224
+    assert emu.emu_plan_lengths(12, 3600, 1, 3, 600, ctypes.byref(lh), ctypes.byref(lw)) == 0
+    assert lw.value >= 4199 and emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) == 0
 
 
 # ------------------------------------------------------------------------------------ GPU tier
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_gpu_fast_kernels_all_variants(fftconv, oracle, monkeypatch, variant):
-    set_variant(monkeypatch, variant)
+def test_gpu_fast_kernels_all_variants(fftconv, oracle, variant):
     data, ks = make_inputs(BOTH_SHAPE, 5)
     H, W, F, kh, kw, n = BOTH_SHAPE
-    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
+    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks, options=plan_options(variant))
     assert util.rel_err(got[0], reference(oracle, BOTH_SHAPE, 5)[0]) < 1e-5
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ROW_SHAPES + COL_SHAPES)
-@pytest.mark.parametrize("mode", [1, 2, 3])
-def test_gpu_fast_kernels_one_dimension(fftconv, oracle, monkeypatch, shape, mode):
-    set_variant(monkeypatch, (mode, 16, 0, 0))
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gpu_fast_kernels_one_dimension(fftconv, oracle, shape, mode):
     H, W, F, kh, kw, n = shape
     data, ks = make_inputs(shape, 23)
-    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
+    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks, options=plan_options((mode, -1)))
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < 1e-5
 
@@ -178,11 +183,10 @@ def test_gpu_fast_kernels_one_dimension(fftconv, oracle, monkeypatch, shape, mod
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", OTHER_SHAPES)
 @pytest.mark.parametrize("mode", [1, 2])
-def test_gpu_fast_kernels_other_configs(fftconv, oracle, monkeypatch, shape, mode):
-    set_variant(monkeypatch, (mode, 16, 0, 0, 1, 0, mode - 1))
+def test_gpu_fast_kernels_other_configs(fftconv, oracle, shape, mode):
     H, W, F, kh, kw, n = shape
     data, ks = make_inputs(shape, 31)
-    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks)
+    got = fftconv.cudaConvolutionFFT(data, kh, kw, ks, options=plan_options((mode, -1)))
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
         assert util.rel_err(g, r) < 1e-5
 
@@ -209,15 +213,14 @@ def test_gpu_fast_kernels_many_maps_multi_feature(fftconv, oracle):
                                    (256, 256, 1, 31, 31, 7), (300, 4096, 1, 20, 63, 11),
                                    (512, 512, 1, 31, 31, 7), (720, 640, 1, 21, 31, 7), (1280, 720, 1, 63, 47, 7),
                                    (200, 3000, 1, 31, 65, 7), (150, 6000, 1, 9, 70, 7), (120, 8192, 1, 7, 127, 7)])
-def test_gpu_multi_map_row_kernel(fftconv, oracle, monkeypatch, shape, group):
+def test_gpu_multi_map_row_kernel(fftconv, oracle, shape, group):
     """several maps per workgroup with DISTINCT kernels (walk indexing, prefetch of the next kernel
     row, partial last walk: 7 = 2+2+2+1 = 5+2) on every fast row configuration"""
-    set_variant(monkeypatch, (2, 16, 0, 0, 1, 0, 1, group))
     H, W, F, kh, kw, n = shape
     rng = np.random.default_rng(1000 + group)
     data = rng.random((H, W, F), dtype=np.float32)
     ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(n)]
-    with fftconv.Plan(H, W, F, kh, kw) as p:
+    with fftconv.Plan(H, W, F, kh, kw, options=plan_options((2, group))) as p:
         p.set_image(data)
         got = p.convolve(ks)
     for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
@@ -225,9 +228,8 @@ def test_gpu_multi_map_row_kernel(fftconv, oracle, monkeypatch, shape, group):
 
 
 @pytest.mark.gpu
-def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle, monkeypatch):
+def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle):
     """enough maps that the per-launch choice walks several maps per workgroup (cfg1-sized maps)"""
-    set_variant(monkeypatch, (2, 16, 0, 0, 1, 0, 1, -1))
     H, W, kh, kw, n = 256, 256, 31, 31, 1500
     rng = np.random.default_rng(99)
     data = rng.random((H, W, 1), dtype=np.float32)
@@ -242,62 +244,52 @@ def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle, monkeypa
         assert util.rel_err(got[i], r) < 1e-5
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("size,k", [(6000, 63), (8192, 127)])
-def test_gpu_big_square_walk_with_remainder(fftconv, monkeypatch, size, k):
-    """both dimensions on the 6144 / 8448 configurations (two row workgroups per CU, 4-column output
-    tiles, cropped window at 6000), 17 kernels = one full walk of 16 + a remainder of 1.  The float64
-    oracle needs minutes at this size, so the specialised path is compared with the generic kernels
-    (path mode 0, themselves pinned to the oracle at every smaller size) on the same inputs."""
+def _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, expect_transform, sample):
+    """device-resident maps of the specialised path (default) against the generic kernels
+    (kernel_path 1) on the same inputs"""
     torch = pytest.importorskip("torch")
-    H = W = size
-    n = 17
-    rng = np.random.default_rng(size)
-    data = rng.random((H, W, 1), dtype=np.float32)
-    ks = [rng.random((k, k, 1), dtype=np.float32) for _ in range(n)]
     kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(x, (2, 1, 0)) for x in ks]))).cuda()
     maps = {}
     for mode in (2, 0):
-        set_variant(monkeypatch, (mode, 16, 0, 0))
-        with fftconv.Plan(H, W, 1, k, k) as p:
+        with fftconv.Plan(H, W, 1, kh, kw, options=plan_options((mode, -1))) as p:
             if mode == 2:
-                assert p.info.transform_h == p.info.transform_w and p.info.transform_h in (6144, 8448)
+                assert expect_transform(p.info.transform_h, p.info.transform_w)
             p.set_image(data)
             od = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device="cuda")
-            p.convolve_packed_device(n, kd.data_ptr(), k, k, od.data_ptr())
+            p.convolve_packed_device(n, kd.data_ptr(), kh, kw, od.data_ptr())
             p.synchronize()
-            maps[mode] = [od[j].cpu().numpy() for j in (0, 7, n - 1)]
+            maps[mode] = [od[j].cpu().numpy() for j in sample]
             del od
     for a, b in zip(maps[2], maps[0]):
         assert util.rel_err(a, b) < 1e-5
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,k", [(6000, 63), (8192, 127)])
+def test_gpu_big_square_walk_with_remainder(fftconv, size, k):
+    """both dimensions on the 6144 / 8448 configurations (two row workgroups per CU, 4-column output
+    tiles, cropped window at 6000), 17 kernels = one full walk of 16 + a remainder of 1.  The float64
+    oracle needs minutes at this size, so the specialised path is compared with the generic kernels
+    (kernel_path 1, themselves pinned to the oracle at every smaller size) on the same inputs."""
+    H = W = size
+    n = 17
+    rng = np.random.default_rng(size)
+    data = rng.random((H, W, 1), dtype=np.float32)
+    ks = [rng.random((k, k, 1), dtype=np.float32) for _ in range(n)]
+    _specialised_vs_generic(fftconv, H, W, k, k, n, data, ks, lambda lh, lw: lh == lw and lh in (6144, 8448), (0, 7, n - 1))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lh,lw", [(288, 288), (576, 768), (768, 576), (1152, 1536), (1536, 1152), (2112, 3072), (3072, 2112),
                                    (4224, 576), (768, 4224), (6144, 288), (288, 6144), (8448, 768), (1536, 8448), (2112, 2112)])
-def test_gpu_every_fast_length_pair_vs_generic(fftconv, monkeypatch, lh, lw):
+def test_gpu_every_fast_length_pair_vs_generic(fftconv, lh, lw):
     """both kernels specialised, every transform length at least once along h and along w, 17
-    kernels (multi-map walk + remainder), odd data sizes: specialised path (mode 2) against the
-    generic kernels (mode 0) on the same inputs"""
-    torch = pytest.importorskip("torch")
+    kernels (multi-map walk + remainder), odd data sizes: specialised path against the generic
+    kernels on the same inputs"""
     kh, kw = 9 + lh // 64, 7 + lw // 96
     H, W = lh - kh + 1 - 3, lw - kw + 1 - 5
     n = 17
     rng = np.random.default_rng(lh * 10007 + lw)
     data = rng.standard_normal((H, W, 1)).astype(np.float32)
     ks = [rng.standard_normal((kh, kw, 1)).astype(np.float32) for _ in range(n)]
-    kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(x, (2, 1, 0)) for x in ks]))).cuda()
-    maps = {}
-    for mode in (2, 0):
-        set_variant(monkeypatch, (mode, 16, 0, 0))
-        with fftconv.Plan(H, W, 1, kh, kw) as p:
-            if mode == 2:
-                assert (p.info.transform_h, p.info.transform_w) == (lh, lw)
-            p.set_image(data)
-            od = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device="cuda")
-            p.convolve_packed_device(n, kd.data_ptr(), kh, kw, od.data_ptr())
-            p.synchronize()
-            maps[mode] = od.cpu().numpy()
-            del od
-    for j in range(n):
-        assert util.rel_err(maps[2][j], maps[0][j]) < 1e-5
+    _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, lambda a, b: (a, b) == (lh, lw), range(n))

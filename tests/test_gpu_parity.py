@@ -79,6 +79,19 @@ def test_demo_invariants(fc):
     assert np.abs(got[0][n + cn - 1:, :]).max() < TOL * np.abs(got[0]).max()
 
 
+def test_demo_planted_template_peaks(fc):
+    """demoCudaConvolutionFFT.m:57-69 on the GPU path: the planted templates answer at their offsets
+    shifted by (cn-1, cm-1), with sum(template^2) = 22140 at the peak (one-shot entry and flip_kernels plan)"""
+    data, cn, cm, ks, _ = golden_util.load_case("case_demo")
+    golden_util.demo_planted_checks(lambda kernels: fc.cudaConvolutionFFT(data, cn, cm, kernels), data, cn, cm, ks, 1e-5)
+    # the same through a plan that does the demo's "Flip Kernel (Required)" step itself
+    with fc.Plan(data.shape[0], data.shape[1], data.shape[2], cn, cm) as plan:
+        plan.set_option("flip_kernels", 1)
+        plan.set_image(data)
+        golden_util.demo_planted_checks(lambda kernels: plan.convolve([np.ascontiguousarray(k[::-1, ::-1, :]) for k in kernels]),
+                                        data, cn, cm, ks, 1e-5)
+
+
 def test_empty_cell(fc):
     assert fc.cudaConvolutionFFT(np.zeros((8, 8, 1), np.float32), 3, 3, []) == []
 
@@ -275,6 +288,58 @@ def test_cfg3_full_size_properties(fc, oracle):
     assert util.rel_err(out[0].cpu().numpy().T, ref) < TOL
 
 
+def test_cfg3_headline_launch_geometry(fc, oracle):
+    """The launch geometry bench.py times (BASELINE configs[2]): 4096x4096 image, 127x127 kernels,
+    84 kernels in one call = one full 64-map launch (four walks of 16 maps per workgroup of the
+    spectral-row kernel) + a 20-map launch (shorter walks), the persistent output kernel over
+    64 x 528 and 20 x 528 tiles.  Every map is checked on the device -- checksum identity
+    sum(map) = sum(image) * sum(kernel), a delta kernel (shifted image), linear combinations of
+    earlier kernels -- and three sampled maps (first launch, launch boundary, second launch)
+    against the oracle (src/cudaConvolutionFFT.cu:204-291 is the loop this batches)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H = W = 4096
+    kh = kw = 127
+    n = 84
+    g = torch.Generator(device="cpu").manual_seed(1234 + 33)
+    img = torch.rand((1, W, H), generator=g, dtype=torch.float32)
+    ks = torch.rand((n, 1, kw, kh), generator=g, dtype=torch.float32)
+    ks[17].zero_(); ks[17, 0, 100, 3] = 1.0               # delta at (h = 3, w = 100): inside the first launch
+    ks[70].zero_(); ks[70, 0, 0, 126] = 1.0               # delta at (h = 126, w = 0): second launch
+    combos = {40: (2.0, 5, -3.0, 31), 66: (0.5, 63, 1.5, 64), 83: (-1.0, 0, 4.0, 79)}   # j -> a * k[p] + b * k[q], across walks and launches
+    for j, (a, p_, b, q_) in combos.items():
+        ks[j] = a * ks[p_] + b * ks[q_]
+    out = _device_run(fc, torch, img.to(dev), ks.to(dev), kh, kw)
+    assert tuple(out.shape) == (n, 4224, 4224)
+    img_d = img.to(dev)
+    # checksum identity, all maps
+    s_img = float(img.double().sum())
+    s_ker = ks.double().sum(dim=(1, 2, 3))
+    s_map = out.sum(dim=(1, 2), dtype=torch.float64).cpu()
+    want = s_img * s_ker
+    assert float(((s_map - want).abs() / want.abs()).max()) < 1e-5
+    # delta kernels -> the image shifted, zero elsewhere
+    for j, (dh, dw) in {17: (3, 100), 70: (126, 0)}.items():
+        w_ = torch.zeros((4224, 4224), dtype=torch.float32, device=dev)
+        w_[dw:dw + W, dh:dh + H] = img_d[0]
+        assert float((out[j] - w_).abs().max()) < TOL
+        del w_
+    # linear combinations against the maps of their terms
+    for j, (a, p_, b, q_) in combos.items():
+        d = (out[j].double() - (a * out[p_].double() + b * out[q_].double())).abs().max()
+        assert float(d) / float(out[j].abs().max()) < TOL
+    # nothing outside the linear support (4222 x 4222), any map
+    scale = float(out.abs().amax())
+    assert float(out[:, 4222:, :].abs().amax()) / scale < TOL and float(out[:, :, 4222:].abs().amax()) / scale < TOL
+    # sampled maps against the oracle
+    idx = [15, 63, 64]
+    img_np = np.asfortranarray(np.transpose(img.numpy(), (2, 1, 0)))
+    k_np = [np.asfortranarray(np.transpose(ks[j].numpy(), (2, 1, 0))) for j in idx]
+    ref = oracle.conv_fft(img_np, kh, kw, k_np)
+    for j, r in zip(idx, ref):
+        assert util.rel_err(out[j].cpu().numpy().T, r) < TOL
+
+
 def test_cfg4_and_cfg5_geometry_vs_oracle(fc, oracle):
     """BASELINE configs[3] (4160x4160 maps, 63x63 kernels) and configs[4] (2048x2048 image ->
     2112x2112): one map each against the oracle."""
@@ -390,14 +455,14 @@ def test_flip_kernels_option_equals_flipping_by_hand(fc, oracle):
 # ---- block-wise (overlap-add) one-shot path for sizes beyond one plan ------------------------------
 
 @pytest.mark.parametrize("shape", [
-    (150, 40, 2, 9, 7, 3),      # h tiled only (FFTCONV_MAX_TRANSFORM = 64: blocks of 56 x W)
+    (150, 40, 2, 9, 7, 3),      # h tiled only (max_transform = 64: blocks of 56 x W)
     (40, 170, 1, 5, 11, 2),     # w tiled only
     (130, 140, 2, 12, 10, 3),   # both: 3 x 3 blocks, ragged edges
     (57, 57, 1, 9, 9, 1),       # one sample more than a block
 ])
-def test_blockwise_one_shot_matches_oracle(fc, oracle, monkeypatch, shape):
+def test_blockwise_one_shot_matches_oracle(fc, oracle, shape):
     """fftconv_convolution_fft falls back to overlap-add over ordinary plans when the padded size
-    does not fit one plan; FFTCONV_MAX_TRANSFORM (test hook) makes small problems take that path."""
+    does not fit one plan; fftconv_plan_options.max_transform makes small problems take that path."""
     H, W, F, kh, kw, n = shape
     rng = np.random.default_rng(sum(shape))
     data = rng.standard_normal((H, W, F)).astype(np.float32)
@@ -406,18 +471,18 @@ def test_blockwise_one_shot_matches_oracle(fc, oracle, monkeypatch, shape):
         ks[1] = rng.standard_normal((kh - 2, kw - 1, F)).astype(np.float32)      # ragged cell
     ref = oracle.conv_fft(data, kh, kw, ks)
     direct = fc.cudaConvolutionFFT(data, kh, kw, ks)
-    monkeypatch.setenv("FFTCONV_MAX_TRANSFORM", "64")
+    small = {"max_transform": 64}
     with pytest.raises(fc.FFTConvError) as ei:
-        fc.Plan(H, W, F, kh, kw)                       # the plan API itself reports the limit
+        fc.Plan(H, W, F, kh, kw, options=small)        # the plan API itself reports the limit
     assert ei.value.status == -5
-    got = fc.cudaConvolutionFFT(data, kh, kw, ks)
+    got = fc.cudaConvolutionFFT(data, kh, kw, ks, options=small)
     for g, d, r in zip(got, direct, ref):
         assert g.shape == r.shape
         assert util.rel_err(g, r) < TIGHT
         assert util.rel_err(g, d) < TIGHT
     # kernels beyond MAX_KERNEL cannot be folded block-wise: rejected, not wrapped
     with pytest.raises(fc.FFTConvError) as ei:
-        fc.cudaConvolutionFFT(data, kh - 1, kw, ks)
+        fc.cudaConvolutionFFT(data, kh - 1, kw, ks, options=small)
     assert ei.value.status == -4
 
 

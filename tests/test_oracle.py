@@ -74,3 +74,25 @@ def test_demo_invariants(oracle):
     assert np.abs(got[0][n + cn - 1:, :]).max() < 1e-9 and np.abs(got[0][:, m + cm - 1:]).max() < 1e-9
     # cropped part equals sum_i conv2(data_i, kernel_i)  (:91-96,149-155)
     assert util.rel_err(got[0][:n + cn - 1, :m + cm - 1], expect[0][:n + cn - 1, :m + cm - 1]) < 1e-12
+
+
+def test_demo_planted_template_peaks(oracle):
+    """demoCudaConvolutionFFT.m:57-69: response peaks at the planted offsets shifted by (cn-1, cm-1),
+    peak value sum(template^2) = 22140 exactly (float64)"""
+    data, cn, cm, ks, _ = golden_util.load_case("case_demo")
+    golden_util.demo_planted_checks(lambda kernels: oracle.conv_fft(data, cn, cm, kernels, f64=True), data, cn, cm, ks, 1e-12)
+    # and the fp32 half-spectrum CPU restatement (second CPU baseline) on the same structure
+    c32 = util.CpuF32()
+    golden_util.demo_planted_checks(lambda kernels: c32.conv_fft(data, cn, cm, kernels), data, cn, cm, ks, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4, 3), (100, 90, 2, 7, 9, 2), (272, 300, 3, 17, 33, 2), (1024, 1024, 1, 63, 63, 1)])
+def test_cpu_f32_baseline_matches_oracle(oracle, shape):
+    """oracle/fftconv_cpu_f32.cpp (fp32, half spectra: the second CPU baseline bench.py times) against
+    the float64 oracle, ragged cell included"""
+    H, W, F, kh, kw, n = shape
+    img, ks = util.synth(5, H, W, F, kh, kw, n)
+    ks[-1] = np.asfortranarray(ks[-1][:max(1, kh - 2), :max(1, kw - 3), :])
+    got = util.CpuF32().conv_fft(img, kh, kw, ks)
+    for g, r in zip(got, oracle.conv_fft(img, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5

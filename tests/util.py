@@ -84,6 +84,29 @@ class Oracle:
         return out
 
 
+class CpuF32:
+    """ctypes view of oracle/libcpu_f32.so: the fp32 half-spectrum CPU restatement (second CPU
+    baseline of SURVEY.md 8(d)); same contract as Oracle.conv_fft."""
+
+    def __init__(self):
+        d = os.path.join(ROOT, "oracle")
+        so = os.path.join(d, "libcpu_f32.so")
+        if not os.path.exists(so):
+            _build(so, d)
+        self.lib = ctypes.CDLL(so)
+
+    def conv_fft(self, data, mkh, mkw, kernels, threads=0):
+        d, ks, n, kp, kh, kw = Oracle._prep(data, kernels)
+        H, W, F = d.shape
+        fh, fw = ceil16(H + mkh - 1), ceil16(W + mkw - 1)
+        outs = [np.zeros((fh, fw), dtype=np.float32, order="F") for _ in range(n)]
+        op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        rc = self.lib.cpu_f32_conv_fft(ctypes.c_void_p(d.ctypes.data), H, W, F, mkh, mkw, n, kp, kh, kw, op, threads)
+        if rc != 0:
+            raise ValueError("cpu_f32_conv_fft rc=%d" % rc)
+        return outs
+
+
 def numpy_fft_conv(data, mkh, mkw, kernels):
     """Independent float64 statement of demoCudaConvolutionFFT.m:78-102 with NumPy's pocketfft."""
     data = np.asarray(data, dtype=np.float64)

@@ -1,6 +1,6 @@
-# A/B of the multi-map row kernel: FFTCONV_ROWS_GROUP x batch_maps on a config
+# A/B of the multi-map row kernel: rows_group x batch_maps on a config (arguments group:batch ...)
 CFG=${CFG:-cfg3}
-run() { FFTCONV_ROWS_GROUP=$1 python bench.py --config $CFG --batch-maps $2 --no-cpu-baseline --steps 3 --warmup 1 --check 2>/dev/null | python -c "
+run() { python bench.py --config $CFG --rows-group $1 --batch-maps $2 --no-cpu-baseline --steps 3 --warmup 1 --check 2>/dev/null | python -c "
 import sys,json
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=j['kernels']

@@ -5,7 +5,6 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 dbg = torch.zeros(16 * 8, dtype=torch.int64, device="cuda")
-os.environ["FFTCONV_ROWS_TIMELINE_PTR"] = str(dbg.data_ptr())
 import util
 fc = util.load_package()
 H = W = 4096; kh = kw = 127; n = 64
@@ -13,6 +12,7 @@ img = torch.rand((1, W, H), dtype=torch.float32, device="cuda")
 ker = torch.rand((n, 1, kw, kh), dtype=torch.float32, device="cuda")
 plan = fc.Plan(H, W, 1, kh, kw, stream=torch.cuda.current_stream().cuda_stream)
 out = torch.empty((n, plan.info.fft_w, plan.info.fft_h), dtype=torch.float32, device="cuda")
+plan.set_option("timeline_ptr", dbg.data_ptr())   # exists in FC_*_TIMELINE builds only
 for rep in range(3):
     plan.set_image_device(img.data_ptr())
     plan.convolve_packed_device(n, ker.data_ptr(), kh, kw, out.data_ptr())
