@@ -21,7 +21,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, "libfftconv.so")  # FFTCONV_LIB: kernel experiments
 
-HOST, DEVICE = 0, 1
+HOST, DEVICE, AUTO = 0, 1, 2
 MEX_ERROR_ID = "cudaConvFFTData:InvalidInput"  # src/cudaConvolutionFFT.cu:30
 
 
@@ -52,10 +52,10 @@ class PlanInfo(ctypes.Structure):
 class PlanOptions(ctypes.Structure):
     """fftconv_plan_options (include/fftconv.h): choices fixed at plan creation."""
     _fields_ = [("struct_size", ctypes.c_size_t), ("kernel_path", ctypes.c_int), ("rows_group", ctypes.c_int),
-                ("max_transform", ctypes.c_int)]
+                ("max_transform", ctypes.c_int), ("exact_window", ctypes.c_int)]
 
-    def __init__(self, kernel_path=0, rows_group=0, max_transform=0):
-        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform))
+    def __init__(self, kernel_path=0, rows_group=0, max_transform=0, exact_window=0):
+        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform), int(exact_window))
 
 
 def _options_ptr(options):
@@ -79,11 +79,11 @@ class Profile(ctypes.Structure):
 
 # every symbol include/fftconv.h declares
 EXPORTED_SYMBOLS = (
-    "fftconv_fft_size16", "fftconv_last_error", "fftconv_version", "fftconv_device_count",
+    "fftconv_fft_size16", "fftconv_fft_size_pow2", "fftconv_last_error", "fftconv_version", "fftconv_device_count",
     "fftconv_convolution_fft", "fftconv_convolution_fft_ex", "fftconv_plan_create", "fftconv_plan_create_ex",
     "fftconv_plan_is_live", "fftconv_plan_destroy", "fftconv_plan_get_info",
     "fftconv_plan_set_image", "fftconv_plan_spectrum", "fftconv_plan_mark_spectrum_valid",
-    "fftconv_plan_use_spectrum_buffer",
+    "fftconv_plan_use_spectrum_buffer", "fftconv_plan_export_spectrum", "fftconv_plan_import_spectrum",
     "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_prepare_kernels_packed",
     "fftconv_plan_synchronize", "fftconv_plan_set_stream",
     "fftconv_plan_set_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
@@ -128,11 +128,12 @@ def load_library():
     vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     pi = ctypes.POINTER(ctypes.c_int)
     lib.fftconv_fft_size16.argtypes = [ci]
+    lib.fftconv_fft_size_pow2.argtypes = [ci]
     lib.fftconv_last_error.restype = ctypes.c_char_p
     lib.fftconv_version.restype = ctypes.c_char_p
     lib.fftconv_device_count.argtypes = [pi]
     lib.fftconv_convolution_fft.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, pi, pi]
-    lib.fftconv_convolution_fft_ex.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, pi, pi, vp]
+    lib.fftconv_convolution_fft_ex.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp, pi, pi, vp]
     lib.fftconv_plan_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, vp]
     lib.fftconv_plan_create_ex.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, vp, vp]
     lib.fftconv_plan_is_live.argtypes = [vp]
@@ -142,6 +143,8 @@ def load_library():
     lib.fftconv_plan_spectrum.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(cs)]
     lib.fftconv_plan_mark_spectrum_valid.argtypes = [vp]
     lib.fftconv_plan_use_spectrum_buffer.argtypes = [vp, vp, cs]
+    lib.fftconv_plan_export_spectrum.argtypes = [vp, vp, ci]
+    lib.fftconv_plan_import_spectrum.argtypes = [vp, vp, ci]
     lib.fftconv_plan_convolve.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci]
     lib.fftconv_plan_convolve_packed.argtypes = [vp, ci, vp, ci, ci, vp]
     lib.fftconv_plan_prepare_kernels_packed.argtypes = [vp, ci, vp, ci, ci]
@@ -171,6 +174,11 @@ def _check(rc):
 def fft_size16(n):
     """computeFFTsize16 (src/cudaConvFFTData.h:96-102)."""
     return load_library().fftconv_fft_size16(int(n))
+
+
+def fft_size_pow2(n):
+    """computeFFTsize (src/cudaConvFFTData.h:67-94)."""
+    return load_library().fftconv_fft_size_pow2(int(n))
 
 
 def device_count():
@@ -227,7 +235,7 @@ def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None
     ofh, ofw = ctypes.c_int(0), ctypes.c_int(0)
     oref, _okeep = _options_ptr(options)
     _check(lib.fftconv_convolution_fft_ex(ctypes.c_void_p(d.ctypes.data), H, W, F, int(maxKernelH), int(maxKernelW),
-                                          n, kptr, kh, kw, kf, tptr, tn, int(gpuId), optr,
+                                          n, kptr, kh, kw, kf, HOST, tptr, tn, int(gpuId), optr,
                                           ctypes.byref(ofh), ctypes.byref(ofw), oref))
     assert (ofh.value, ofw.value) == (fh, fw)
     return outs
@@ -280,6 +288,23 @@ class Plan:
         p, n = ctypes.c_void_p(None), ctypes.c_size_t(0)
         _check(self._lib.fftconv_plan_spectrum(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def export_spectrum(self):
+        """the image spectrum in the reference's order (what cudaFFTData returns, src/cudaFFTData.cu:
+        90-103): complex64 [F][FFT_W][FFT_H/2+1], unnormalised, == numpy.fft.rfft2 of the padded
+        [F][FFT_W][FFT_H] planes.  Needs a plan created with exact_window."""
+        i = self.info
+        a = np.empty((i.feature_dim, i.fft_w, i.fft_h // 2 + 1), dtype=np.complex64)
+        _check(self._lib.fftconv_plan_export_spectrum(self._h, ctypes.c_void_p(a.ctypes.data), HOST))
+        return a
+
+    def import_spectrum(self, spectrum):
+        """replaces set_image: a spectrum in the reference's order (see export_spectrum)"""
+        i = self.info
+        a = np.ascontiguousarray(spectrum, dtype=np.complex64)
+        if a.shape != (i.feature_dim, i.fft_w, i.fft_h // 2 + 1):
+            raise FFTConvError(-1, "spectrum must be [F][FFT_W][FFT_H/2+1], got %s" % (a.shape,))
+        _check(self._lib.fftconv_plan_import_spectrum(self._h, ctypes.c_void_p(a.ctypes.data), HOST))
 
     def use_spectrum_buffer(self, ptr, nbytes):
         """keep the image spectrum in caller-owned device memory (e.g. a torch tensor)"""

@@ -66,6 +66,7 @@ PlanTuning tuning_from(const fftconv_plan_options* o) {
     t.path_mode = o->kernel_path == 1 ? 0 : o->kernel_path == 2 ? 1 : 2;
     t.rows_group = o->rows_group <= 0 ? -1 : o->rows_group;
     t.max_transform = o->max_transform > 0 ? o->max_transform : 0;
+    t.exact_window = o->exact_window != 0;
     return t;
 }
 
@@ -292,6 +293,8 @@ struct fftconv_plan {
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
     DevBuf<int> fc_rowoff, fc_pair_row_of;
+    DevBuf<int> nat_row_of, nat_col_of;   // natural-order spectrum exchange (uploaded on first use)
+    DevBuf<c32> NS;                       // its device staging for host callers
     int num_cus = 256;
     long opt_batch_maps = 0;
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
@@ -362,6 +365,7 @@ struct fftconv_plan {
         S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); OC.release(); I.release();
         fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_pair_row_of.release();
+        nat_row_of.release(); nat_col_of.release(); NS.release();
     }
 };
 
@@ -594,7 +598,9 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
                 HIP_TRY(launch_cols_c2r(ca, tiles_for(g.fft_w, T), ny, cthreads, p->cols_lds(), p->stream));
             }
             if (int rc = p->prof_end()) return rc;
-            if (cropped)
+            if (cropped && p->opt_region == 4)
+                HIP_TRY(launch_pad_maps(p->O.p, g.fft_h, g.fft_w, g.map_elems(), dest, p->out_h, p->out_w, oe, ny, p->stream));
+            else if (cropped)
                 HIP_TRY(launch_crop_maps(p->O.p, g.fft_h, g.map_elems(), dest, p->out_h, p->out_w, oe, p->off_h, p->off_w, ny, p->stream));
             if (streamed) {
                 HIP_TRY(hipEventRecord(p->ring->compute_done[buf], p->stream));
@@ -652,7 +658,7 @@ int check_thread_size(const double* thread_size, int n_thread_size) {
 // and the blocks partition the image).  The block spectra are computed once and kept; kernels are
 // processed in chunks that fit a few GiB of device maps.
 int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int mkw, int n, const float* const* kernels, const int* kh,
-                          const int* kw, int gpu_id, float* const* out, const fftconv_plan_options* options) {
+                          const int* kw, int kernel_location, int gpu_id, float* const* out, const fftconv_plan_options* options) {
     int limit = 4224;
     if (options && options->struct_size >= sizeof(fftconv_plan_options) && options->max_transform > 0) limit = std::min(limit, options->max_transform);
     for (int k = 0; k < n; k++)
@@ -709,7 +715,7 @@ int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int m
             const int y0 = (b % nbh) * Bh, x0 = (b / nbh) * Bw;
             if ((rc = fftconv_plan_use_spectrum_buffer(sub, specs.p + (size_t)b * spec_elems, spec_elems * sizeof(c32)))) return finish(rc);
             if ((rc = fftconv_plan_mark_spectrum_valid(sub))) return finish(rc);
-            if ((rc = fftconv_plan_convolve(sub, nk, kernels + k0, kh + k0, kw + k0, FFTCONV_HOST, tptr.data(), FFTCONV_DEVICE))) return finish(rc);
+            if ((rc = fftconv_plan_convolve(sub, nk, kernels + k0, kh + k0, kw + k0, kernel_location, tptr.data(), FFTCONV_DEVICE))) return finish(rc);
             hipError_t e = launch_add_window(big.p, FH, FW, big_map, y0, x0, tmp.p, g.fft_h, g.fft_w, blk_map, nk, sub->stream);
             if (e != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "overlap-add failed: %s", hipGetErrorString(e)));
         }
@@ -726,6 +732,7 @@ int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int m
 extern "C" {
 
 int fftconv_fft_size16(int data_size) { return fft_size16(data_size); }
+int fftconv_fft_size_pow2(int data_size) { return fft_size_pow2(data_size); }
 
 const char* fftconv_last_error(void) { return g_last_error.c_str(); }
 
@@ -914,6 +921,47 @@ int fftconv_plan_spectrum(fftconv_plan* plan, void** device_ptr, size_t* bytes) 
     return 0;
 }
 
+static int spectrum_exchange(fftconv_plan* p, float* spectrum, int location, bool to_natural) {
+    if (!p || !spectrum) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (location != FFTCONV_HOST && location != FFTCONV_DEVICE) return fail(FFTCONV_ERR_INVALID_ARG, "bad location");
+    const Geometry& g = p->g;
+    if (!g.exact_window)
+        return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
+                    "this plan transforms %dx%d, not the %dx%d window: create it with fftconv_plan_options.exact_window = 1 to exchange "
+                    "spectra in the reference's order", g.Lh, g.Lw, g.fft_h, g.fft_w);
+    if (to_natural && !p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
+    if (int rc = use_device(p)) return rc;
+    if (int rc = p->ensure_spectrum()) return rc;
+    if (!p->nat_row_of.p) {
+        if (int rc = p->nat_row_of.ensure(p->t.nat_row_of.size())) return rc;
+        if (int rc = p->nat_col_of.ensure(p->t.nat_col_of.size())) return rc;
+        HIP_TRY(hipMemcpy(p->nat_row_of.p, p->t.nat_row_of.data(), p->t.nat_row_of.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->nat_col_of.p, p->t.nat_col_of.data(), p->t.nat_col_of.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    const size_t n = (size_t)g.F * g.fft_w * g.rows;
+    c32* nat = reinterpret_cast<c32*>(spectrum);
+    if (location == FFTCONV_HOST) {
+        if (int rc = p->NS.ensure(n)) return rc;
+        nat = p->NS.p;
+        if (!to_natural) HIP_TRY(hipMemcpyAsync(nat, spectrum, n * sizeof(c32), hipMemcpyHostToDevice, p->stream));
+    }
+    // the folded 1/(Lh*Lw) of src/cudaConvolutionFFT.cu:270 comes off on the way out and goes on on the way in
+    const double norm = (double)g.Lh * (double)g.Lw;
+    HIP_TRY(launch_spectrum_reorder(to_natural, p->spec(), (size_t)g.rows * g.s_pitch, g.s_pitch, nat, g.fft_w, g.rows, g.F,
+                                    p->nat_row_of.p, p->nat_col_of.p, (float)(to_natural ? norm : 1.0 / norm), p->stream));
+    if (location == FFTCONV_HOST) {
+        if (to_natural) HIP_TRY(hipMemcpyAsync(spectrum, nat, n * sizeof(c32), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    if (!to_natural) p->have_image = true;
+    return 0;
+}
+
+int fftconv_plan_export_spectrum(fftconv_plan* plan, float* spectrum, int location) { return spectrum_exchange(plan, spectrum, location, true); }
+int fftconv_plan_import_spectrum(fftconv_plan* plan, const float* spectrum, int location) {
+    return spectrum_exchange(plan, const_cast<float*>(spectrum), location, false);
+}
+
 int fftconv_plan_use_spectrum_buffer(fftconv_plan* plan, void* device_ptr, size_t bytes) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     if (device_ptr) {
@@ -985,7 +1033,8 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
         if (int rc = p->K.ensure(per * n)) return rc;
         for (int j = 0; j < n; j++)
             HIP_TRY(hipMemcpyAsync(p->K.p + per * j, kernels[k0 + j], per * sizeof(float),
-                                   kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                                   kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice
+                                   : kernel_location == FFTCONV_AUTO ? hipMemcpyDefault : hipMemcpyDeviceToDevice,
                                    p->stream));
         Sink sink;
         sink.ptrs = out + k0;
@@ -1030,7 +1079,8 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         if (value == 1) { oh = g.H + g.max_kh - 1; ow = g.W + g.max_kw - 1; }
         else if (value == 2) { oh = g.H; ow = g.W; fh = (g.max_kh - 1) / 2; fw = (g.max_kw - 1) / 2; }
         else if (value == 3) { oh = g.H - g.max_kh + 1; ow = g.W - g.max_kw + 1; fh = g.max_kh - 1; fw = g.max_kw - 1; }
-        else if (value != 0) return fail(FFTCONV_ERR_INVALID_ARG, "output_region is 0 (window), 1 (full), 2 (same) or 3 (valid)");
+        else if (value == 4) { oh = fft_size_pow2(g.H + g.max_kh - 1); ow = fft_size_pow2(g.W + g.max_kw - 1); }
+        else if (value != 0) return fail(FFTCONV_ERR_INVALID_ARG, "output_region is 0 (window), 1 (full), 2 (same), 3 (valid) or 4 (pow2 window)");
         if (oh < 1 || ow < 1) return fail(FFTCONV_ERR_INVALID_ARG, "output_region %ld is empty for %dx%d data and %dx%d kernels", value, g.H, g.W, g.max_kh, g.max_kw);
         if (int rc = use_device(plan)) return rc;
         HIP_TRY(hipStreamSynchronize(plan->stream));
@@ -1070,13 +1120,16 @@ int fftconv_convolution_fft(const float* data, int data_h, int data_w, int featu
                             const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
                             int gpu_id, float* const* out, int* fft_h, int* fft_w) {
     return fftconv_convolution_fft_ex(data, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, n_kernel, kernels, kernel_h,
-                                      kernel_w, kernel_f, thread_size, n_thread_size, gpu_id, out, fft_h, fft_w, nullptr);
+                                      kernel_w, kernel_f, FFTCONV_HOST, thread_size, n_thread_size, gpu_id, out, fft_h, fft_w, nullptr);
 }
 
 int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int feature_dim, int max_kernel_h,
                                int max_kernel_w, int n_kernel, const float* const* kernels, const int* kernel_h,
-                               const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
-                               int gpu_id, float* const* out, int* fft_h, int* fft_w, const fftconv_plan_options* options) {
+                               const int* kernel_w, const int* kernel_f, int kernel_location, const double* thread_size,
+                               int n_thread_size, int gpu_id, float* const* out, int* fft_h, int* fft_w,
+                               const fftconv_plan_options* options) {
+    if (kernel_location != FFTCONV_HOST && kernel_location != FFTCONV_DEVICE && kernel_location != FFTCONV_AUTO)
+        return fail(FFTCONV_ERR_INVALID_ARG, "bad kernel location");
     // argument checks in the reference's order (src/cudaConvolutionFFT.cu:45-89)
     if (!data || data_h < 1 || data_w < 1 || feature_dim < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
     if (n_kernel < 0 || (n_kernel > 0 && (!kernels || !kernel_h || !kernel_w || !out)))
@@ -1094,11 +1147,11 @@ int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int fe
         // too large for one single-pass plan: block-wise (overlap-add) over ordinary plans
         if (rc == FFTCONV_ERR_UNSUPPORTED_SIZE && n_kernel > 0)
             return tiled_convolution_fft(data, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, n_kernel, kernels, kernel_h,
-                                         kernel_w, gpu_id, out, options);
+                                         kernel_w, kernel_location, gpu_id, out, options);
         return rc;
     }
     int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);
-    if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, FFTCONV_HOST, out, FFTCONV_HOST);
+    if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, kernel_location, out, FFTCONV_HOST);
     std::string keep = g_last_error;
     fftconv_plan_destroy(p);
     if (rc) g_last_error = keep;
@@ -1125,14 +1178,14 @@ int fftconv_fft_data(const float* data, int data_h, int data_w, int feature_dim,
 int fftconv_conv_fft_data(fftconv_plan* fft_data, int n_kernel, const float* const* kernels, const int* kernel_h,
                           const int* kernel_w, const int* kernel_f, const double* thread_size, int n_thread_size,
                           float* const* out) {
-    if (!fft_data) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid input to MEX file.");  // src/cudaConvFFTData.cu:68
+    if (!fft_data || !fftconv_plan_is_live(fft_data)) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid input to MEX file.");  // src/cudaConvFFTData.cu:68
     if (int rc = check_thread_size(thread_size, n_thread_size)) return rc;
     if (kernel_f)
         for (int k = 0; k < n_kernel; k++)
             if (kernel_f[k] != fft_data->g.F)
                 return fail(FFTCONV_ERR_KERNEL_SHAPE,
                             "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
-    return fftconv_plan_convolve(fft_data, n_kernel, kernels, kernel_h, kernel_w, FFTCONV_HOST, out, FFTCONV_HOST);
+    return fftconv_plan_convolve(fft_data, n_kernel, kernels, kernel_h, kernel_w, FFTCONV_AUTO, out, FFTCONV_HOST);
 }
 
 }  // extern "C"

@@ -68,7 +68,52 @@ __global__ void __launch_bounds__(256) k_crop_maps(const float* __restrict__ src
     for (int y = (int)threadIdx.x; y < dst_h; y += (int)blockDim.x) d[y] = s[y];
 }
 
+// Image spectrum between the engine's internal order and the reference's natural order
+// [f][FFT_W][FFT_H/2+1] (cufftExecR2C output, src/cudaFFTData.cu:90-103): natural element (x, y) of
+// plane f is internal element S[f][row_of[y]][col_of[x]]; `scale` undoes / applies the folded
+// normalisation.  A one-off utility: no attempt at coalescing the permuted side.
+template <bool EXPORT>
+__global__ void __launch_bounds__(256) k_spectrum_reorder(c32* __restrict__ S, size_t s_plane, int s_pitch, c32* __restrict__ nat, int fw, int ch,
+                                                          const int* __restrict__ row_of, const int* __restrict__ col_of, float scale) {
+    const int x = (int)blockIdx.x, f = (int)blockIdx.y;
+    const size_t base = (size_t)f * s_plane + col_of[x];
+    c32* n = nat + ((size_t)f * fw + x) * ch;
+    for (int y = (int)threadIdx.x; y < ch; y += (int)blockDim.x) {
+        const size_t i = base + (size_t)row_of[y] * s_pitch;
+        if (EXPORT) n[y] = scale * S[i];
+        else S[i] = scale * n[y];
+    }
+}
+
+// dst map (dst_h x dst_w, contiguous, LARGER than the source) = the src map in its top-left corner,
+// zeros elsewhere: the reference's alternative next-power-of-two window (computeFFTsize,
+// src/cudaConvFFTData.h:67-94) around the ceil16 window the engine computes
+__global__ void __launch_bounds__(256) k_pad_maps(const float* __restrict__ src, int src_h, int src_w, size_t src_map_stride,
+                                                  float* __restrict__ dst, int dst_h, size_t dst_map_stride) {
+    const int x = (int)blockIdx.x, map = (int)blockIdx.y;
+    const float* s = src + (size_t)map * src_map_stride + (size_t)x * src_h;
+    float* d = dst + (size_t)map * dst_map_stride + (size_t)x * dst_h;
+    const int n = x < src_w ? src_h : 0;
+    for (int y = (int)threadIdx.x; y < dst_h; y += (int)blockDim.x) d[y] = y < n ? s[y] : 0.f;
+}
+
 }  // namespace
+
+hipError_t launch_pad_maps(const float* src, int src_h, int src_w, size_t src_map_stride, float* dst, int dst_h, int dst_w,
+                           size_t dst_map_stride, int nmaps, hipStream_t s) {
+    if (nmaps <= 0 || dst_h <= 0 || dst_w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pad_maps, dim3((unsigned)dst_w, (unsigned)nmaps), dim3(256), 0, s, src, src_h, src_w, src_map_stride, dst, dst_h,
+                       dst_map_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrum_reorder(bool to_natural, c32* S, size_t s_plane, int s_pitch, c32* nat, int fw, int ch, int planes,
+                                   const int* row_of, const int* col_of, float scale, hipStream_t s) {
+    if (fw <= 0 || ch <= 0 || planes <= 0) return hipSuccess;
+    if (to_natural) hipLaunchKernelGGL(k_spectrum_reorder<true>, dim3((unsigned)fw, (unsigned)planes), dim3(256), 0, s, S, s_plane, s_pitch, nat, fw, ch, row_of, col_of, scale);
+    else hipLaunchKernelGGL(k_spectrum_reorder<false>, dim3((unsigned)fw, (unsigned)planes), dim3(256), 0, s, S, s_plane, s_pitch, nat, fw, ch, row_of, col_of, scale);
+    return hipGetLastError();
+}
 
 hipError_t launch_flip_planes(const float* src, float* dst, int plane_elems, long nplanes, hipStream_t s) {
     const long total = (long)plane_elems * nplanes;

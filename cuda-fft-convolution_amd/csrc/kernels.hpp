@@ -18,6 +18,12 @@ hipError_t launch_add_window(float* dst, int dst_h, int dst_w, size_t dst_map_st
 // dst[map] (dst_h x dst_w, contiguous) = window of src[map] at (off_h, off_w); src has src_h rows per column
 hipError_t launch_crop_maps(const float* src, int src_h, size_t src_map_stride, float* dst, int dst_h, int dst_w, size_t dst_map_stride,
                             int off_h, int off_w, int nmaps, hipStream_t s);
+// natural [f][fw][ch] <-> internal image-spectrum order (see kernels.hip: k_spectrum_reorder)
+hipError_t launch_spectrum_reorder(bool to_natural, c32* S, size_t s_plane, int s_pitch, c32* nat, int fw, int ch, int planes,
+                                   const int* row_of, const int* col_of, float scale, hipStream_t s);
+// dst[map] (dst_h x dst_w >= src) = src[map] in the top-left corner, zero elsewhere
+hipError_t launch_pad_maps(const float* src, int src_h, int src_w, size_t src_map_stride, float* dst, int dst_h, int dst_w,
+                           size_t dst_map_stride, int nmaps, hipStream_t s);
 hipError_t launch_cols_r2c(const ColsR2CArgs& a, int tiles, int planes, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);

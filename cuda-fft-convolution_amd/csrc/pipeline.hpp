@@ -27,6 +27,9 @@ struct PlanTuning {
     // largest transform length a plan may use (0 = whatever fits the LDS); larger problems are left
     // to the block-wise path of the one-shot entry
     int max_transform = 0;
+    // transform lengths must equal the ceil16 window (the reference's circular modulus; needed to
+    // exchange spectra in the reference's order); unsupported windows then fail
+    bool exact_window = false;
 };
 
 struct Geometry {
@@ -82,6 +85,8 @@ struct Tables {
     std::vector<PairEntry> pairs;
     FastRowsTables fr;  // only if Geometry::fast_rows.ok
     FastColsTables fcl; // only if Geometry::fast_cols.ok
+    // natural h-frequency y -> spectrum row, natural w-frequency x -> element of a stored image-spectrum row
+    std::vector<int> nat_row_of, nat_col_of;
 };
 
 // returns false if the sizes are invalid / unsupported
@@ -102,6 +107,11 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (allow_fast) { prefs.fast_rows = &fast_rows_length; prefs.fast_cols = &fast_cols_length; prefs.max_kw = max_kw; }
     g.Lh = choose_length(H + max_kh - 1, true, g.fft_h, prefs);
     g.Lw = choose_length(W + max_kw - 1, false, g.fft_w, prefs);
+    if (tune.exact_window) {
+        if (!length_supported(g.fft_h / 2) || !length_supported(g.fft_w)) return false;
+        g.Lh = g.fft_h;
+        g.Lw = g.fft_w;
+    }
     if (g.Lh < 2 || g.Lw < 1) return false;
     if (tune.max_transform > 0 && (g.Lh > tune.max_transform || g.Lw > tune.max_transform)) return false;
     g.M = g.Lh / 2;
@@ -128,6 +138,16 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     // the plan whose digit-reversed order the spectrum rows are produced in
     Plan1D producer = g.fast_fwd ? make_plan1d_seq(g.M, {g.fast_cols.R1, g.fast_cols.R2, g.fast_cols.R3}) : t.pm;
     if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, producer, g.y_pitch);
+    t.nat_row_of.assign(g.rows, g.M);                       // bin M (Nyquist) lives in the extra row M
+    for (int k = 0; k < g.M; k++) t.nat_row_of[k] = producer.pos[k];
+    t.nat_col_of.assign(g.Lw, 0);
+    if (g.fast_rows.ok) {                                   // stored element x holds transform position relayout[x]
+        std::vector<int> inv(g.Lw, 0);
+        for (int x = 0; x < g.Lw; x++) inv[t.fr.relayout[x]] = x;
+        for (int k = 0; k < g.Lw; k++) t.nat_col_of[k] = inv[t.pw.pos[k]];
+    } else {
+        for (int k = 0; k < g.Lw; k++) t.nat_col_of[k] = t.pw.pos[k];
+    }
     return true;
 }
 

@@ -23,6 +23,14 @@ inline int fft_size16(int n) {  // src/cudaConvFFTData.h:96-102
     return mod * 16 + (rem > 0 ? 16 : 0);
 }
 
+// The reference's alternative sizing (computeFFTsize, src/cudaConvFFTData.h:67-94; unused by its
+// shipped path): align up to 16, then up to the next power of two.
+inline int fft_size_pow2(int n) {
+    int v = fft_size16(n), p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
 // Relative cost of one stage of radix R per element (butterfly + twiddle + LDS round trip).
 inline double radix_cost(int R) {
     switch (R) {

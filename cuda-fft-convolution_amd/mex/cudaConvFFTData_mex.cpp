@@ -10,6 +10,15 @@
 
 #include "fftconv.h"
 #include "mex.h"
+#if defined(__has_include)
+#if __has_include("gpu/mxGPUArray.h")
+#include "gpu/mxGPUArray.h"   // MathWorks GPU MEX API: gpuArray kernels (src/cudaConvolutionFFT.cu:224-238)
+#define FFTCONV_MEX_GPU 1
+#endif
+#endif
+#ifndef FFTCONV_MEX_GPU
+#define FFTCONV_MEX_GPU 0
+#endif
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const char* errId = FFTCONV_MEX_ERROR_ID;   // "cudaConvFFTData:InvalidInput" (src/cudaConvFFTData.cu:47)
@@ -24,20 +33,49 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
     if (mxGetClassID(prhs[1]) != mxCELL_CLASS) mexErrMsgIdAndTxt(errId, "Kernel must be a cell array");   // :108-109
     fftconv_plan* plan = reinterpret_cast<fftconv_plan*>((uintptr_t) * static_cast<const uint64_t*>(mxGetData(prhs[0])));
+    // a handle cudaFFTData released, one from before `clear mex`, or any stray uint64: refused, not dereferenced
+    if (!fftconv_plan_is_live(plan)) mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");
     fftconv_plan_info info;
     if (fftconv_plan_get_info(plan, &info) != FFTCONV_OK) mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
     const int n = (int)mxGetNumberOfElements(prhs[1]);
     std::vector<const float*> kp(n);
     std::vector<int> kh(n), kw(n), kf(n);
+    bool any_gpu = false;
+#if FFTCONV_MEX_GPU
+    std::vector<const mxGPUArray*> views;   // released before every way out (mexErrMsg* does not run destructors in MATLAB)
+    auto release_views = [&] { for (const mxGPUArray* g : views) mxGPUDestroyGPUArray(g); views.clear(); };
+#else
+    auto release_views = [] {};
+#endif
+    auto bad_kernel = [&] {
+        release_views();
+        mexErrMsgIdAndTxt(errId, "Kernels must be of type float and have features larger than 1");
+    };
     for (int k = 0; k < n; k++) {
         const mxArray* c = mxGetCell(prhs[1], k);
-        const mwSize knd = c ? mxGetNumberOfDimensions(c) : 0;
-        if (!c || mxGetClassID(c) != mxSINGLE_CLASS || knd < 2 || knd > 3)
-            mexErrMsgIdAndTxt(errId, "Kernels must be of type float and have features larger than 1");   // :150-151
-        const mwSize* kd = mxGetDimensions(c);
-        kp[k] = static_cast<const float*>(mxGetData(c));
+        if (!c) bad_kernel();
+        const mwSize* kd = nullptr;
+        mwSize knd = 0;
+#if FFTCONV_MEX_GPU
+        if (mxIsGPUArray(c)) {                                                              // gpuArray kernel (reference src/cudaConvFFTData.cu:153-167)
+            const mxGPUArray* g = mxGPUCreateFromMxArray(c);
+            views.push_back(g);
+            knd = mxGPUGetNumberOfDimensions(g);
+            if (mxGPUGetClassID(g) != mxSINGLE_CLASS || knd < 2 || knd > 3) bad_kernel();
+            kd = mxGPUGetDimensions(g);
+            kp[k] = static_cast<const float*>(mxGPUGetDataReadOnly(g));                     
+            any_gpu = true;
+        } else
+#endif
+        {
+            knd = mxGetNumberOfDimensions(c);
+            if (mxGetClassID(c) != mxSINGLE_CLASS || knd < 2 || knd > 3) bad_kernel();   // reference: "Kernels must be of type float ..."
+            kd = mxGetDimensions(c);
+            kp[k] = static_cast<const float*>(mxGetData(c));
+        }
         kh[k] = (int)kd[0]; kw[k] = (int)kd[1]; kf[k] = knd == 3 ? (int)kd[2] : 1;
     }
+    (void)any_gpu;   // fftconv_conv_fft_data tells host and device kernels apart itself (FFTCONV_AUTO)
     plhs[0] = mxCreateCellMatrix(1, n);                                                      // :112
     std::vector<float*> out(n);
     const mwSize cdims[2] = {(mwSize)info.fft_h, (mwSize)info.fft_w};
@@ -46,6 +84,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         out[k] = static_cast<float*>(mxGetData(m));
         mxSetCell(plhs[0], k, m);
     }
-    if (fftconv_conv_fft_data(plan, n, kp.data(), kh.data(), kw.data(), kf.data(), threads, nthreads, out.data()) != FFTCONV_OK)
-        mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
+    const int rc = fftconv_conv_fft_data(plan, n, kp.data(), kh.data(), kw.data(), kf.data(), threads, nthreads, out.data());
+    release_views();
+    if (rc != FFTCONV_OK) mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
 }

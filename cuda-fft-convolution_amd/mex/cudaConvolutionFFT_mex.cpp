@@ -6,15 +6,27 @@
 // Build on a host with MATLAB (mex.h is not present in the development image, so this file is
 // not part of the default build):
 //   mex -largeArrayDims -I<repo>/include cudaConvolutionFFT_mex.cpp -L<repo>/cuda-fft-convolution_amd -lfftconv
-// gpuArray kernels (src/cudaConvolutionFFT.cu:224-238) would additionally need mxGPUArray.h and
-// fftconv_plan_convolve(..., FFTCONV_DEVICE, ...); host arrays are handled here.
+// Cells may mix host single arrays and gpuArrays (src/cudaConvolutionFFT.cu:207-238); the gpuArray
+// branch is compiled where the MathWorks GPU header gpu/mxGPUArray.h is on the include path.
 #include <vector>
 
 #include "fftconv.h"
 #include "mex.h"
+#if defined(__has_include)
+#if __has_include("gpu/mxGPUArray.h")
+#include "gpu/mxGPUArray.h"   // MathWorks GPU MEX API: gpuArray kernels (src/cudaConvolutionFFT.cu:224-238)
+#define FFTCONV_MEX_GPU 1
+#endif
+#endif
+#ifndef FFTCONV_MEX_GPU
+#define FFTCONV_MEX_GPU 0
+#endif
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const char* errId = FFTCONV_MEX_ERROR_ID;  // "cudaConvFFTData:InvalidInput" (reference :30)
+#if FFTCONV_MEX_GPU
+    mxInitGPU();                                                                             // :40
+#endif
     if (nrhs < 4 || nrhs > 6) mexErrMsgIdAndTxt(errId, "Wrong number of inputs");          // :45-46
     const mxArray* mxDATA = prhs[0];
     const mwSize nd = mxGetNumberOfDimensions(mxDATA);
@@ -31,13 +43,39 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 
     std::vector<const float*> kp(n);
     std::vector<int> kh(n), kw(n), kf(n);
+    bool any_gpu = false;
+#if FFTCONV_MEX_GPU
+    std::vector<const mxGPUArray*> views;   // released before every way out (mexErrMsg* does not run destructors in MATLAB)
+    auto release_views = [&] { for (const mxGPUArray* g : views) mxGPUDestroyGPUArray(g); views.clear(); };
+#else
+    auto release_views = [] {};
+#endif
+    auto bad_kernel = [&] {
+        release_views();
+        mexErrMsgIdAndTxt(errId, "Kernels must be of type float and have features larger than 1");
+    };
     for (int k = 0; k < n; k++) {
         const mxArray* c = mxGetCell(prhs[3], k);
-        const mwSize knd = mxGetNumberOfDimensions(c);
-        if (mxGetClassID(c) != mxSINGLE_CLASS || knd < 2 || knd > 3)
-            mexErrMsgIdAndTxt(errId, "Kernels must be of type float and have features larger than 1");  // :210-211
-        const mwSize* kd = mxGetDimensions(c);
-        kp[k] = (const float*)mxGetData(c);
+        if (!c) bad_kernel();
+        const mwSize* kd = nullptr;
+        mwSize knd = 0;
+#if FFTCONV_MEX_GPU
+        if (mxIsGPUArray(c)) {                                                              // gpuArray kernel (reference :224-238)
+            const mxGPUArray* g = mxGPUCreateFromMxArray(c);
+            views.push_back(g);
+            knd = mxGPUGetNumberOfDimensions(g);
+            if (mxGPUGetClassID(g) != mxSINGLE_CLASS || knd < 2 || knd > 3) bad_kernel();
+            kd = mxGPUGetDimensions(g);
+            kp[k] = static_cast<const float*>(mxGPUGetDataReadOnly(g));                     // :237
+            any_gpu = true;
+        } else
+#endif
+        {
+            knd = mxGetNumberOfDimensions(c);
+            if (mxGetClassID(c) != mxSINGLE_CLASS || knd < 2 || knd > 3) bad_kernel();   // reference: "Kernels must be of type float ..."
+            kd = mxGetDimensions(c);
+            kp[k] = static_cast<const float*>(mxGetData(c));
+        }
         kh[k] = (int)kd[0]; kw[k] = (int)kd[1]; kf[k] = knd == 3 ? (int)kd[2] : 1;
     }
     const int FFT_H = fftconv_fft_size16(H + maxKH - 1), FFT_W = fftconv_fft_size16(W + maxKW - 1);
@@ -49,7 +87,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         out[k] = (float*)mxGetData(m);
         mxSetCell(plhs[0], k, m);                                                            // :288
     }
-    int rc = fftconv_convolution_fft((const float*)mxGetData(mxDATA), H, W, F, maxKH, maxKW, n, kp.data(), kh.data(),
-                                     kw.data(), kf.data(), threads, nthreads, gpu, out.data(), nullptr, nullptr);
+    int rc = fftconv_convolution_fft_ex((const float*)mxGetData(mxDATA), H, W, F, maxKH, maxKW, n, kp.data(), kh.data(),
+                                        kw.data(), kf.data(), any_gpu ? FFTCONV_AUTO : FFTCONV_HOST, threads, nthreads, gpu, out.data(),
+                                        nullptr, nullptr, nullptr);
+    release_views();
     if (rc != FFTCONV_OK) mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
 }

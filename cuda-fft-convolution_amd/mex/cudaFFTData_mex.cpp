@@ -31,7 +31,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nrhs == 1 && mxGetClassID(prhs[0]) == mxUINT64_CLASS && mxGetNumberOfElements(prhs[0]) == 1) {
         fftconv_plan* p = reinterpret_cast<fftconv_plan*>((uintptr_t) * static_cast<const uint64_t*>(mxGetData(prhs[0])));
         auto it = std::find(g_live.begin(), g_live.end(), p);
-        if (it == g_live.end()) mexErrMsgIdAndTxt(errId, errMsg);
+        if (it == g_live.end() || !fftconv_plan_is_live(p)) mexErrMsgIdAndTxt(errId, errMsg);
         g_live.erase(it);
         fftconv_plan_destroy(p);
         return;

@@ -49,10 +49,18 @@ typedef enum fftconv_status {
 /* Error id the MEX gateway raises for argument errors (src/cudaConvolutionFFT.cu:30). */
 #define FFTCONV_MEX_ERROR_ID "cudaConvFFTData:InvalidInput"
 
-enum { FFTCONV_HOST = 0, FFTCONV_DEVICE = 1 };
+enum { FFTCONV_HOST = 0, FFTCONV_DEVICE = 1,
+       FFTCONV_AUTO = 2 /* kernels of fftconv_plan_convolve only: every pointer may be host or device memory, the
+                           HIP runtime tells them apart (a cell mixing host arrays and gpuArrays:
+                           src/cudaConvolutionFFT.cu:207-238) */ };
 
 /* computeFFTsize16 (src/cudaConvFFTData.h:96-102): round up to a multiple of 16. */
 int fftconv_fft_size16(int data_size);
+
+/* computeFFTsize (src/cudaConvFFTData.h:67-94), the reference's alternative sizing: up to a
+ * multiple of 16, then up to the next power of two.  Its shipped path never calls it; plans offer
+ * it as "output_region" 4. */
+int fftconv_fft_size_pow2(int data_size);
 
 /* Message of the last failure on this thread ("" if none). */
 const char *fftconv_last_error(void);
@@ -93,12 +101,15 @@ int fftconv_convolution_fft(const float *data, int data_h, int data_w, int featu
                             const double *thread_size, int n_thread_size,
                             int gpu_id,
                             float *const *out, int *fft_h, int *fft_w);
-/* The same with plan options (forward-declared below; NULL = defaults). */
+/* The same with plan options (forward-declared below; NULL = defaults) and kernels that may be
+ * device-resident: kernel_location FFTCONV_HOST, FFTCONV_DEVICE, or FFTCONV_AUTO for a cell that
+ * mixes host arrays and gpuArrays as the reference's loop allows (src/cudaConvolutionFFT.cu:207-238). */
 struct fftconv_plan_options;
 int fftconv_convolution_fft_ex(const float *data, int data_h, int data_w, int feature_dim,
                                int max_kernel_h, int max_kernel_w,
                                int n_kernel, const float *const *kernels,
                                const int *kernel_h, const int *kernel_w, const int *kernel_f,
+                               int kernel_location,
                                const double *thread_size, int n_thread_size,
                                int gpu_id,
                                float *const *out, int *fft_h, int *fft_w,
@@ -148,6 +159,10 @@ typedef struct fftconv_plan_options {
     int max_transform;  /* > 0: largest transform length a plan may use; creation fails with
                          *    FFTCONV_ERR_UNSUPPORTED_SIZE beyond it and the one-shot entry goes block-wise
                          *    (overlap-add) with blocks of at most this size */
+    int exact_window;   /* 1: the transform lengths must be the ceil16 window FFT_H x FFT_W itself (the
+                         *    reference's circular modulus, plan_info.exact_window = 1) -- what
+                         *    fftconv_plan_export_spectrum / _import_spectrum need; creation fails with
+                         *    FFTCONV_ERR_UNSUPPORTED_SIZE when the window has a prime factor above 17 */
 } fftconv_plan_options;
 int fftconv_plan_create_ex(fftconv_plan **plan, int data_h, int data_w, int feature_dim,
                            int max_kernel_h, int max_kernel_w, int gpu_id, void *hip_stream,
@@ -175,6 +190,17 @@ int fftconv_plan_mark_spectrum_valid(fftconv_plan *plan);
  * buffer).  Lets a communication library that owns its buffers (torch.distributed / RCCL)
  * broadcast the spectrum with no staging copy.  Invalidates the current spectrum. */
 int fftconv_plan_use_spectrum_buffer(fftconv_plan *plan, void *device_ptr, size_t bytes);
+
+/* The image spectrum in the reference's own order: what cudaFFTData returns as a complex single
+ * gpuArray of (FFT_H/2+1) x FFT_W x F (src/cudaFFTData.cu:90-103,150), i.e. cufftExecR2C's output
+ * [f][FFT_W][FFT_H/2+1] (src/cudaConvolutionFFT.cu:122-142: the halved dimension is h), unnormalised,
+ * interleaved (re, im) floats; spectrum_natural_bytes = 8 * F * FFT_W * (FFT_H/2+1).
+ * export: after fftconv_plan_set_image; import: replaces set_image (a spectrum the caller kept or
+ * edited).  Both need a plan whose transform is the window (fftconv_plan_options.exact_window, or
+ * plan_info.exact_window = 1 anyway) and return FFTCONV_ERR_UNSUPPORTED_SIZE otherwise.
+ * location: FFTCONV_HOST or FFTCONV_DEVICE; synchronous for host memory. */
+int fftconv_plan_export_spectrum(fftconv_plan *plan, float *spectrum, int location);
+int fftconv_plan_import_spectrum(fftconv_plan *plan, const float *spectrum, int location);
 
 /* Per-kernel loop of src/cudaConvolutionFFT.cu:204-291 for arbitrary (possibly different)
  * kernel sizes.  kernels[k]: kh[k] x kw[k] x F, host or device (gpuArray kernels: :224-238);
@@ -222,8 +248,10 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             MAX_KERNEL sizes K: 0 (default) the whole FFT_H x FFT_W window as the reference
  *             returns it; 1 "full" = the linear convolution, (DATA + K - 1), what the demo crops by
  *             hand (demoCudaConvolutionFFT.m:149); 2 "same" = DATA-sized, centred; 3 "valid" =
- *             DATA - K + 1, no zero padding involved.  Result buffers then hold out_h x out_w
- *             floats (fftconv_plan_get_info)),
+ *             DATA - K + 1, no zero padding involved; 4 "pow2 window" = fftconv_fft_size_pow2(DATA + K - 1)
+ *             per dimension, the window the reference's unused computeFFTsize would give
+ *             (src/cudaConvFFTData.h:67-94): the convolution in its top-left corner, zeros elsewhere.
+ *             Result buffers then hold out_h x out_w floats (fftconv_plan_get_info)),
  *          "flip_kernels" (1: every kernel is flipped along h and w on the device before it is
  *             transformed, i.e. the plan correlates -- the "Flip Kernel (Required)" step of
  *             demoCudaConvolutionFFT.m:63-69 done here instead of in MATLAB; the reference keeps a
@@ -247,6 +275,8 @@ int fftconv_plan_get_profile(fftconv_plan *plan, fftconv_profile *prof, int rese
  * ------------------------------------------------------------------------------------------ */
 int fftconv_fft_data(const float *data, int data_h, int data_w, int feature_dim,
                      int kernel_h, int kernel_w, int gpu_id, fftconv_plan **fft_data);
+/* (kernels of fftconv_conv_fft_data: host arrays or device-resident ones, told apart by the HIP
+ *  runtime -- FFTCONV_AUTO -- as src/cudaConvFFTData.cu accepts gpuArray cells too) */
 int fftconv_conv_fft_data(fftconv_plan *fft_data, int n_kernel, const float *const *kernels,
                           const int *kernel_h, const int *kernel_w, const int *kernel_f,
                           const double *thread_size, int n_thread_size, float *const *out);

@@ -2,6 +2,7 @@
 // API so that the Python tests can build argument lists, call a gateway's mexFunction and read the
 // results or the raised error.  Test infrastructure: never linked into the product.
 #include "mex.h"
+#include "gpu/mxGPUArray.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -15,7 +16,15 @@ struct mxArray_tag {
     std::vector<mwSize> dims;
     std::vector<unsigned char> data;
     std::vector<mxArray*> cells;
+    // a gpuArray: the data lives in device memory (dev), MATLAB reports an opaque class for the mxArray itself
+    bool on_gpu = false;
+    mxClassID gpu_cls = mxUNKNOWN_CLASS;
+    void* dev = nullptr;
 };
+struct mxGPUArray_tag {
+    const mxArray* src;
+};
+int g_live_gpu_views = 0;
 
 namespace {
 struct MexError {
@@ -35,7 +44,15 @@ extern "C" {
 
 mwSize mxGetNumberOfDimensions(const mxArray* a) { return a->dims.size(); }
 const mwSize* mxGetDimensions(const mxArray* a) { return a->dims.data(); }
-mxClassID mxGetClassID(const mxArray* a) { return a->cls; }
+mxClassID mxGetClassID(const mxArray* a) { return a->on_gpu ? mxUNKNOWN_CLASS : a->cls; }
+int mxInitGPU(void) { return MX_GPU_SUCCESS; }
+int mxIsGPUArray(const mxArray* a) { return a && a->on_gpu ? 1 : 0; }
+const mxGPUArray* mxGPUCreateFromMxArray(const mxArray* a) { g_live_gpu_views++; return new mxGPUArray_tag{a}; }
+mxClassID mxGPUGetClassID(const mxGPUArray* g) { return g->src->gpu_cls; }
+mwSize mxGPUGetNumberOfDimensions(const mxGPUArray* g) { return g->src->dims.size(); }
+const mwSize* mxGPUGetDimensions(const mxGPUArray* g) { return g->src->dims.data(); }
+const void* mxGPUGetDataReadOnly(const mxGPUArray* g) { return g->src->dev; }
+void mxGPUDestroyGPUArray(const mxGPUArray* g) { g_live_gpu_views--; delete g; }
 size_t mxGetNumberOfElements(const mxArray* a) { return count(a); }
 void* mxGetData(const mxArray* a) { return const_cast<unsigned char*>(a->data.data()); }
 double mxGetScalar(const mxArray* a) {
@@ -95,6 +112,17 @@ mxArray* mock_new_numeric(int cls, int ndim, const uint64_t* dims, const void* d
     if (data) memcpy(a->data.data(), data, a->data.size());
     return a;
 }
+// a gpuArray of class `cls` whose elements live at device pointer `dev` (owned by the test)
+mxArray* mock_new_gpu(int cls, int ndim, const uint64_t* dims, void* dev) {
+    mxArray* a = new mxArray_tag();
+    a->dims.assign(dims, dims + ndim);
+    while (a->dims.size() < 2) a->dims.push_back(1);
+    a->on_gpu = true;
+    a->gpu_cls = (mxClassID)cls;
+    a->dev = dev;
+    return a;
+}
+int mock_live_gpu_views(void) { return g_live_gpu_views; }   // mxGPUCreateFromMxArray not yet destroyed
 mxArray* mock_new_cell(int n) { return mxCreateCellMatrix(1, n); }
 void mock_set_cell(mxArray* c, int i, mxArray* v) { mxSetCell(c, i, v); }
 mxArray* mock_get_cell(mxArray* c, int i) { return mxGetCell(c, i); }

@@ -538,6 +538,35 @@ def test_output_regions_match_slices_of_the_window(fc, oracle, shape):
         assert util.rel_err(back, ref[0]) < TIGHT
 
 
+@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4, 3), (300, 260, 1, 31, 17, 2), (1024, 1024, 1, 63, 63, 1)])
+def test_output_region_pow2_window(fc, oracle, shape):
+    """"output_region" 4: the next-power-of-two window of the reference's computeFFTsize
+    (src/cudaConvFFTData.h:67-94: align to 16, then to a power of two) -- the convolution in the
+    top-left corner, exact zeros in the rest; what a float64 fft2/ifft2 at that size gives too"""
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape) + 4)
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    ph, pw = fc.fft_size_pow2(H + kh - 1), fc.fft_size_pow2(W + kw - 1)
+    assert ph & (ph - 1) == 0 and pw & (pw - 1) == 0 and ph >= util.ceil16(H + kh - 1) and ph < 2 * util.ceil16(H + kh - 1)
+    D = np.fft.fft2(data.astype(np.float64), s=(ph, pw), axes=(0, 1))
+    want = [np.real(np.fft.ifft2(D * np.fft.fft2(k.astype(np.float64), s=(ph, pw), axes=(0, 1)), axes=(0, 1))).sum(axis=2) for k in ks]
+    with fc.Plan(H, W, F, kh, kw) as plan:
+        plan.set_image(data)
+        plan.set_option("output_region", 4)
+        assert (plan.info.out_h, plan.info.out_w) == (ph, pw)
+        got = plan.convolve(ks)
+        for g, r in zip(got, want):
+            assert g.shape == (ph, pw)
+            assert util.rel_err(g, r) < TIGHT
+            assert not g[util.ceil16(H + kh - 1):, :].any() and not g[:, util.ceil16(W + kw - 1):].any()   # beyond the ceil16 window: exact zeros
+
+
+def test_pow2_size_function(fc):
+    # computeFFTsize: iAlignUp(n, 16), already a power of two -> itself, else the next one
+    assert [fc.fft_size_pow2(n) for n in (1, 16, 17, 33, 64, 65, 286, 1086, 4222, 4096)] == [16, 16, 32, 64, 64, 128, 512, 2048, 8192, 4096]
+
+
 def test_output_region_rejects_empty_and_unknown(fc):
     with fc.Plan(20, 20, 1, 31, 5) as plan:
         with pytest.raises(fc.FFTConvError):
@@ -546,3 +575,51 @@ def test_output_region_rejects_empty_and_unknown(fc):
             plan.set_option("output_region", 7)
         plan.set_option("output_region", 1)
         assert (plan.info.out_h, plan.info.out_w) == (50, 24)
+
+
+# ---- the image spectrum in the reference's own order (cudaFFTData's gpuArray) -----------------------
+
+@pytest.mark.parametrize("shape", [
+    (64, 8, 5, 10, 4),          # the demo problem: generic kernels
+    (256, 256, 1, 31, 31),      # cfg1: 288 x 288, both specialised kernels (register-order spectrum rows)
+    (1024, 1024, 1, 63, 63),    # cfg2's 1088 window: exact_window keeps the transform off 1152
+    (500, 4096, 2, 40, 127),    # 4224 along w only, F = 2
+    (300, 200, 3, 21, 9),
+])
+def test_spectrum_export_import_in_reference_order(fc, oracle, shape):
+    """fftconv_plan_export_spectrum == numpy.fft.rfft2 of the zero-padded [F][FFT_W][FFT_H] planes, the
+    layout of the complex gpuArray cudaFFTData returns (src/cudaFFTData.cu:90-103; cuFFT geometry
+    src/cudaConvolutionFFT.cu:122-142); importing it into a fresh plan convolves like set_image."""
+    H, W, F, kh, kw = shape
+    rng = np.random.default_rng(sum(shape))
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(2)]
+    fh, fw = util.ceil16(H + kh - 1), util.ceil16(W + kw - 1)
+    padded = np.zeros((F, fw, fh), dtype=np.float64)
+    padded[:, :W, :H] = np.transpose(data, (2, 1, 0))
+    want = np.fft.rfft2(padded, axes=(1, 2))
+    with fc.Plan(H, W, F, kh, kw, options={"exact_window": 1}) as p:
+        assert p.info.exact_window == 1 and (p.info.transform_h, p.info.transform_w) == (fh, fw)
+        p.set_image(data)
+        spec = p.export_spectrum()
+        assert spec.shape == (F, fw, fh // 2 + 1)
+        assert np.abs(spec - want).max() / np.abs(want).max() < 1e-5
+        ref = oracle.conv_fft(data, kh, kw, ks)
+        for g, r in zip(p.convolve(ks), ref):
+            assert util.rel_err(g, r) < TIGHT
+    with fc.Plan(H, W, F, kh, kw, options={"exact_window": 1}) as q:
+        with pytest.raises(fc.FFTConvError) as ei:
+            q.export_spectrum()                       # nothing to export yet
+        assert ei.value.status == -9
+        q.import_spectrum(want.astype(np.complex64))  # numpy's spectrum in, never saw the image
+        for g, r in zip(q.convolve(ks), ref):
+            assert util.rel_err(g, r) < TIGHT
+
+
+def test_spectrum_export_needs_the_window_transform(fc):
+    with fc.Plan(1024, 1024, 1, 63, 63) as p:          # default plan: 1152 x 1152 transform, 1088 window
+        assert p.info.exact_window == 0
+        p.set_image(np.zeros((1024, 1024, 1), np.float32))
+        with pytest.raises(fc.FFTConvError) as ei:
+            p.export_spectrum()
+        assert ei.value.status == -5

@@ -27,6 +27,8 @@ class Mex:
         self.rt.mock_new_numeric.restype = vp
         self.rt.mock_new_numeric.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
         self.rt.mock_new_cell.restype = vp
+        self.rt.mock_new_gpu.restype = vp
+        self.rt.mock_new_gpu.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
         self.rt.mock_set_cell.argtypes = [vp, ctypes.c_int, vp]
         self.rt.mock_get_cell.restype = vp
         self.rt.mock_get_cell.argtypes = [vp, ctypes.c_int]
@@ -50,6 +52,11 @@ class Mex:
         shape = a.shape if a.ndim >= 2 else (a.shape + (1, 1))[:2]
         dims = (ctypes.c_uint64 * len(shape))(*shape)
         return self.rt.mock_new_numeric(cls, len(shape), dims, a.ctypes.data_as(ctypes.c_void_p))
+
+    def gpu_array(self, tensor, shape, cls=SINGLE):
+        """a gpuArray of MATLAB shape `shape` whose elements are the torch device tensor's memory"""
+        dims = (ctypes.c_uint64 * len(shape))(*shape)
+        return self.rt.mock_new_gpu(cls, len(shape), dims, ctypes.c_void_p(tensor.data_ptr()))
 
     def scalar(self, v):
         return self.numeric(np.array([[float(v)]], dtype=np.float64))
@@ -185,3 +192,55 @@ def test_two_step_gateways_match_one_shot(mex, oracle):
     raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
     assert not raised
     mex.rt.mock_run_at_exit()
+
+
+def test_stale_or_stray_handles_are_refused_not_dereferenced(mex):
+    """cudaConvFFTData checks the uint64 against the library's registry of live plans
+    (fftconv_plan_is_live): a released handle, one from before `clear mex`, or garbage raises the
+    reference's error instead of crashing MATLAB"""
+    data, ks = demo_inputs()
+    kc = mex.cell([mex.numeric(k) for k in ks])
+    for stray in (0, 0xDEADBEEF, 2 ** 47 + 16):
+        raised, (eid, msg) = mex.call("cudaConvFFTData", [mex.numeric(np.array([[stray]], dtype=np.uint64)), kc])
+        assert raised and eid == ERR_ID and msg == "The data must be FFT-ed real array in GPU"
+    # an empty slot in the kernel cell (mxGetCell -> NULL) is an argument error in both gateways
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [mex.numeric(data), mex.scalar(10), mex.scalar(4), mex.rt.mock_new_cell(2)])
+    assert raised and eid == ERR_ID and msg.startswith("Kernels must be of type float")
+
+
+@pytest.mark.gpu
+def test_gpuarray_kernels_and_released_handles(mex, oracle):
+    """kernels as gpuArrays, alone or mixed with host arrays in one cell
+    (src/cudaConvolutionFFT.cu:207-238), through both gateways; every mxGPUArray view the gateway
+    opens is destroyed again; a released handle is refused afterwards"""
+    torch = pytest.importorskip("torch")
+    data, ks = demo_inputs(21)
+    ref = oracle.conv_fft(data, 10, 4, ks)
+    dev = [torch.from_numpy(np.ascontiguousarray(np.transpose(k, (2, 1, 0)))).cuda() for k in ks]   # column-major 10 x 4 x 5 on the device
+    for mixed in (False, True):
+        cells = [mex.gpu_array(t, (10, 4, 5)) for t in dev]
+        if mixed:
+            cells[1] = mex.numeric(ks[1])
+        raised, out = mex.call("cudaConvolutionFFT", [mex.numeric(data), mex.scalar(10), mex.scalar(4), mex.cell(cells)])
+        assert not raised, out
+        for g, r in zip(mex.cell_to_list(out[0], len(ks)), ref):
+            assert util.rel_err(g, r) < 1e-5
+        assert mex.rt.mock_live_gpu_views() == 0
+    # wrong class on the device: the reference's message, views released all the same
+    bad = mex.cell([mex.gpu_array(dev[0], (10, 4, 5), cls=DOUBLE)])
+    raised, (eid, msg) = mex.call("cudaConvolutionFFT", [mex.numeric(data), mex.scalar(10), mex.scalar(4), bad])
+    assert raised and eid == ERR_ID and msg.startswith("Kernels must be of type float")
+    assert mex.rt.mock_live_gpu_views() == 0
+    # two-step gateway with gpuArray kernels
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
+    assert not raised, out
+    handle = out[0]
+    raised, out = mex.call("cudaConvFFTData", [handle, mex.cell([mex.gpu_array(dev[0], (10, 4, 5)), mex.numeric(ks[1]), mex.gpu_array(dev[2], (10, 4, 5))])])
+    assert not raised, out
+    for g, r in zip(mex.cell_to_list(out[0], len(ks)), ref):
+        assert util.rel_err(g, r) < 1e-5
+    assert mex.rt.mock_live_gpu_views() == 0
+    raised, _ = mex.call("cudaFFTData", [handle], nlhs=0)          # release ...
+    assert not raised
+    raised, (eid, msg) = mex.call("cudaConvFFTData", [handle, mex.cell([mex.numeric(k) for k in ks])])
+    assert raised and msg == "The data must be FFT-ed real array in GPU"   # ... and the stale handle is refused
