@@ -188,7 +188,17 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
                     c32* z0 = lds + (2 * t2) * LP;
                     c32* z1 = z0 + LP;
-                    const c32x2 xa = st.pa[r], xb = st.pb[r];
+                    c32x2 xa = st.pa[r], xb = st.pb[r];
+#if (FC_COLS_DBG & 32) && defined(__HIP_DEVICE_COMPILE__)
+                    // timing experiment: the arithmetic an inverse radix-8 w-stage would add while landing
+                    // (about 21 packed operations per unit of two rows x two columns)
+                    for (int dd = 0; dd < 5; dd++) {
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(xa.a) : "v"(xb.a), "v"(xa.b));
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(xa.b) : "v"(xb.b), "v"(xa.a));
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(xb.a) : "v"(xa.a), "v"(xb.b));
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(xb.b) : "v"(xa.b), "v"(xb.a));
+                    }
+#endif
                     if (k == 0) {                     // DC + Nyquist -> packed bin 0
                         z0[pa] = mk(xa.a.x + xb.a.x, xa.a.x - xb.a.x);
                         z1[pa] = mk(xa.b.x + xb.b.x, xa.b.x - xb.b.x);

@@ -18,6 +18,9 @@
 #ifndef FC_ROWS_NO_FOLD
 #define FC_ROWS_NO_FOLD 0      // 1: A/B, forward stage 1 as a phase of its own for every map
 #endif
+#ifndef FC_ROWSM_DBG
+#define FC_ROWSM_DBG 0         // timing experiments only (wrong results): 1 = P5 without its LDS reads and inverse stage-1 arithmetic (stores + fold only)
+#endif
 #ifndef FC_ROWS_TIMELINE
 #define FC_ROWS_TIMELINE 0     // 1: one workgroup stamps the 100 MHz wall clock at every phase boundary (tools/rows_timeline.py)
 #endif
@@ -231,14 +234,19 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     if (rr < RPW && row0 + rr < rows) {
                         const c32* buf = lds + rr * L;
                         c32 p[R1];
-                        power_chain<R1>(st.w1[r], p);
                         c32 v[R1];
+                        if constexpr (FC_ROWSM_DBG & 1) {
+                            static_for<0, R1>([&](auto c_) { v[decltype(c_)::value] = st.s[decltype(c_)::value]; });
+                            if (FOLD && m + 1 < nk && j < kw) power_chain<R1>(st.w1[r], p);
+                        } else {
+                        power_chain<R1>(st.w1[r], p);
                         v[0] = buf[j];
                         static_for<1, R1>([&](auto c_) {
                             constexpr int c = decltype(c_)::value;
                             v[c] = cmulc(buf[c * m1 + j], p[c]);
                         });
                         Dft<R1, +1>::run(v);
+                        }
                         const int jo = tiled ? (j >> g.y_tile_shift) * g.y_tile_elems + (j & ((1 << g.y_tile_shift) - 1)) : j;
                         const unsigned off0 = (unsigned)(st.yoff[r] + jo) * (unsigned)sizeof(c32);
                         if (g.wout >= L) {   // nothing cropped (uniform)

@@ -101,10 +101,21 @@ class FilterShardedConvolver:
         self.ready = [s.event() for _ in range(self.depth)]      # spectrum b complete on this rank
         self.consumed = [s.event() for _ in range(self.depth)]   # the convolve that read buffer b is done
         self.n_sub = self.n_conv = 0
+        self._prepared = -1          # step whose kernels were prepared
+
+    def _prepare(self):
+        """image-independent part of the next convolve (the kernels' column transforms): the engine
+        may run it beside whatever is queued after it -- the image transform or the broadcast"""
+        prep = getattr(self.engine, "prepare_kernels", None)
+        if prep is not None and self._prepared != self.n_conv:
+            prep(self.first, self.count)
+            self._prepared = self.n_conv
 
     def submit(self, image=None):
         if self.n_sub - self.n_conv >= self.depth:
             raise RuntimeError("submit: all %d spectrum buffers hold steps that were not convolved yet" % self.depth)
+        if self.n_sub == self.n_conv:
+            self._prepare()          # nothing in flight: ahead of this step's own image transform
         b = self.n_sub % self.depth
         s = self.engine.sync
         with s.side():
@@ -124,9 +135,7 @@ class FilterShardedConvolver:
             raise RuntimeError("convolve: nothing submitted")
         b = self.n_conv % self.depth
         s = self.engine.sync
-        prep = getattr(self.engine, "prepare_kernels", None)
-        if prep is not None:
-            prep(self.first, self.count)          # does not need the image: overlaps the broadcast
+        self._prepare()                       # (pipelined steps: here, beside the broadcast)
         s.wait(self.ready[b])
         res = self.engine.convolve(self.spec[b], self.first, self.count)
         s.record(self.consumed[b])
@@ -185,6 +194,9 @@ class ImageStreamedConvolver:
             b = i & 1
             if i + 1 < len(host_images):
                 self._upload(1 - b, host_images[i + 1])   # next image's H2D while this one is convolved
+            prep = getattr(self.engine, "prepare_kernels", None)
+            if prep is not None:
+                prep(0, self.n_filters)            # image-independent: may run beside the image transform
             s.wait(self.copied[b])
             self.engine.compute_spectrum(self.spec, self.buf[b])
             s.record(self.consumed[b])

@@ -1,8 +1,12 @@
 #!/bin/bash
 # Profiles of the default bench (cfg3): kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in
-# separate counter passes.  Usage (on the GPU box): bash tools/profile_round.sh r01f
+# separate counter passes, and profiles/traffic.json regenerated from them (stamped with the commit).
+# Usage (on the GPU box, from the repo root): bash tools/profile_round.sh r02k <commit>
+# then copy gpurun_out/prof_<tag>/{bench*.json,kernel_stats.csv,pmc_fetch_write.txt,traffic.json} into profiles/
 set -e
-TAG=${1:-r01x}
+TAG=${1:-r02x}
+COMMIT=${2:-unknown}
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-$OLDPWD}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -14,6 +18,7 @@ find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 ( echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 (cfg3 defaults)";
   echo "# units: KB per dispatch (mean over dispatches of that grid size); gfx950 correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)";
   python3 tools/pmc_summary.py $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") ) > $OUT/pmc_fetch_write.txt
+python3 tools/make_traffic_json.py cfg3 $(find $OUT/pmc_fetch -name "*counter_collection.csv") $(find $OUT/pmc_write -name "*counter_collection.csv") $OUT/bench_under_rocprof.json $TAG $COMMIT $OUT/traffic.json > /dev/null
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
 ls -la $OUT
