@@ -70,6 +70,13 @@ struct Geometry {
         if (rows_group > 1) return std::min(rows_group, nmaps);
         const long groups = (rows + fast_rows.RPW - 1) / fast_rows.RPW;
         const long g = groups * nmaps / ((long)num_cus * 16);
+        if (g < 1) {
+            // small launches: more workgroups than resident slots (4 per CU) but not four rounds of them --
+            // walk just enough maps per workgroup that ONE round covers the launch (cfg2: 2320 -> 870
+            // workgroups, 2.9 -> 2.5 us per map) instead of leaving a mostly empty last round
+            const long slots = (long)num_cus * 4, total = groups * nmaps;
+            return total > slots ? (int)std::min<long>(nmaps, (total + slots - 1) / slots) : 1;
+        }
         return (int)std::max<long>(1, std::min<long>(16, std::min<long>(g, nmaps)));
     }
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }

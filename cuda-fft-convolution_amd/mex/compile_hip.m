@@ -11,8 +11,13 @@ if ~exist(fullfile(pkg, 'libfftconv.so'), 'file')
 end
 if ~exist(fullfile(repo, 'bin'), 'dir'), mkdir(fullfile(repo, 'bin')); end
 names = {'cudaFFTData', 'cudaConvFFTData', 'cudaConvolutionFFT'};
+% gpuArray kernels (src/cudaConvolutionFFT.cu:224-238): the gateways compile that branch when
+% gpu/mxGPUArray.h is found; it lives where cuda_compile.m:48-52 takes it from and needs libmwgpu (:58)
+gpuinc = fullfile(matlabroot, 'toolbox', 'distcomp', 'gpu', 'extern', 'include');
+gpuargs = {};
+if exist(fullfile(gpuinc, 'gpu', 'mxGPUArray.h'), 'file'), gpuargs = {['-I' gpuinc], '-lmwgpu'}; end
 for i = 1:numel(names)
-  mex('-largeArrayDims', ['-I' fullfile(repo, 'include')], ...
+  mex('-largeArrayDims', ['-I' fullfile(repo, 'include')], gpuargs{:}, ...
       fullfile(pkg, 'mex', [names{i} '_mex.cpp']), ...
       ['-L' pkg], '-lfftconv', ['LDFLAGS=$LDFLAGS -Wl,-rpath,' pkg], ...
       '-output', fullfile(repo, 'bin', names{i}));
