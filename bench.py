@@ -172,6 +172,8 @@ def main():
                          "single-GPU, non-streamed steps only")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one spectrum buffer: image transform + broadcast of a step not overlapped with the previous step's maps (A/B)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="single GPU: two spectrum buffers as at N > 1 -- the image transform of step k + 1 on a side stream beside the maps of step k (A/B)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -234,7 +236,7 @@ def main():
         plan.set_option("rows_group", args.rows_group)
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
     # the next image's H2D copy (streamed mode)
-    overlap = streamed or (use_dist and not args.no_overlap)
+    overlap = streamed or ((use_dist or args.overlap) and not args.no_overlap)
     engine = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap)
     out = engine.out
 

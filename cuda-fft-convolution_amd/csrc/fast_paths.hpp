@@ -10,6 +10,7 @@
 #include "fast_cols.hpp"
 #include "fast_cols_fwd.hpp"
 #include "fast_rows.hpp"
+#include "fast_rows_fwd.hpp"
 #include "fast_rows_multi.hpp"
 #include "planner.hpp"
 
@@ -91,6 +92,21 @@ inline bool fast_rows_dispatch(int L, int nz2_needed, Runner&& run) {
     FC_FAST_ROW_CONFIGS(FC_X)
 #undef FC_X
     return false;
+}
+
+// Forward image-row kernel (fast_rows_fwd.hpp): one instantiation per length (the first listed
+// configuration of that length; NZ2 does not matter).  run.template go<Cfg>().
+template <class Runner>
+inline bool fast_rows_fwd_dispatch(int L, Runner&& run) {
+    bool done = false;
+#define FC_X(LL, A, B, C, NTT, RP, NZ)                          \
+    if (!done && L == LL) {                                     \
+        run.template go<RowCfg<LL, A, B, C, NTT, RP>>();        \
+        done = true;                                            \
+    }
+    FC_FAST_ROW_CONFIGS(FC_X)
+#undef FC_X
+    return done;
 }
 
 // Host tables of a fast row configuration.

@@ -903,9 +903,13 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
     }
     if (int rc = p->prof_end()) return rc;
-    RowsFwdArgs ra = image_rows_args(g, p->t, p->d, sgen);
     if (int rc = p->prof_begin(PK_IMAGE_ROWS, g.F)) return rc;
-    HIP_TRY(launch_rows_fwd(ra, g.F * g.rows, rows_threads(g), (size_t)g.Lw * sizeof(c32), p->stream));
+    if (g.fast_rows.ok) {
+        HIP_TRY(launch_fast_rows_fwd(g.Lw, fast_rows_fwd_args(g, p->d, sgen), g.F * g.rows, p->stream));
+    } else {
+        RowsFwdArgs ra = image_rows_args(g, p->t, p->d, sgen);
+        HIP_TRY(launch_rows_fwd(ra, g.F * g.rows, rows_threads(g), (size_t)g.Lw * sizeof(c32), p->stream));
+    }
     if (int rc = p->prof_end()) return rc;
     if (location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
     p->have_image = true;

@@ -26,6 +26,8 @@ hipError_t launch_pad_maps(const float* src, int src_h, int src_w, size_t src_ma
                            size_t dst_map_stride, int nmaps, hipStream_t s);
 hipError_t launch_cols_r2c(const ColsR2CArgs& a, int tiles, int planes, int threads, size_t lds_bytes, hipStream_t s);
 hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t lds_bytes, hipStream_t s);
+// specialised forward image rows (fast_rows_fwd.hpp); hipErrorInvalidValue if L has no configuration
+hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s);
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 // fast path (fast_rows.hpp); hipErrorInvalidValue if no instantiation matches (L, nz2)
 hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s);

@@ -58,7 +58,37 @@ struct FastRowsLauncher {
     }
 };
 
+template <class Cfg>
+__global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_fwd(FastRowsFwdArgs a, int rows) {
+    DevPhaseCtx<RowFwdState> ctx;
+    fast_rows_fwd_body<Cfg>(ctx, reinterpret_cast<c32*>(fc_smem), a, (int)blockIdx.x, rows);
+}
+
+struct FastRowsFwdLauncher {
+    const FastRowsFwdArgs& a;
+    int rows;
+    hipStream_t s;
+    hipError_t err = hipSuccess;
+    template <class Cfg>
+    void go() {
+        static unsigned long long attr_mask = 0;
+        const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
+        err = ensure_lds_attr(k_fast_rows_fwd<Cfg>, attr_mask);
+        if (err != hipSuccess) return;
+        const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
+        hipLaunchKernelGGL((k_fast_rows_fwd<Cfg>), dim3(groups), dim3(Cfg::NT), lds, s, a, rows);
+        err = hipGetLastError();
+    }
+};
+
 }  // namespace
+
+hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    FastRowsFwdLauncher l{a, rows, s};
+    if (!fast_rows_fwd_dispatch(L, l)) return hipErrorInvalidValue;
+    return l.err;
+}
 
 hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s) {
     if (rows <= 0 || kernels <= 0) return hipSuccess;

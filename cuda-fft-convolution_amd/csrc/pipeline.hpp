@@ -194,6 +194,15 @@ inline RowsFwdArgs image_rows_args(const Geometry& g, const Tables& t, const Dev
     return a;
 }
 
+// the same pass by the specialised kernel (fast_rows_fwd.hpp), when the row length has one
+inline FastRowsFwdArgs fast_rows_fwd_args(const Geometry& g, const DeviceTables& d, c32* S) {
+    FastRowsFwdArgs a{};
+    a.S = S; a.pitch = g.s_pitch; a.nvalid = g.W;
+    a.scale = (float)(1.0 / ((double)g.Lh * (double)g.Lw));
+    a.tw1 = d.fr_tw1; a.tw2 = d.fr_tw2;
+    return a;
+}
+
 // kernel columns of a group of same-sized kernels, packed [n][f][kw][kh]: planes = nk*F
 inline int a_pitch_for(int kw) { return round_up(kw, 8); }
 

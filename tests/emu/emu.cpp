@@ -81,6 +81,20 @@ struct EmuFastRows {
     }
 };
 
+struct EmuFastRowsFwd {
+    const FastRowsFwdArgs& a;
+    c32* lds;
+    int rows;
+    template <class Cfg>
+    void go() {
+        for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
+            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
+            HostPhaseCtx<RowFwdState> ctx(Cfg::NT);
+            fast_rows_fwd_body<Cfg>(ctx, lds, a, grp, rows);
+        }
+    }
+};
+
 struct EmuFastColsFwd {
     const FastColsFwdArgs& a;
     c32* lds;
@@ -151,7 +165,14 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
         for (int plane = 0; plane < F; plane++)
             for (int tile = 0; tile < tiles_for(W, g.T_cols); tile++) cols_r2c_body(ctx, lds.data(), ia, tile, plane);
     }
-    if (g.fast_rows.ok) d.fr_relayout = t.fr.relayout.data();   // w-pass stores in the fast row kernel's order
+    if (g.fast_rows.ok) {   // specialised forward rows: stores in the fast row kernel's register order
+        d.fr_tw1 = t.fr.tw1.data();
+        d.fr_tw2 = t.fr.tw2.data();
+        FastRowsFwdArgs fa = fast_rows_fwd_args(g, d, S);
+        EmuFastRowsFwd run{fa, lds.data(), F * g.rows};
+        if (!fast_rows_fwd_dispatch(g.Lw, run)) return -9;
+        return 0;
+    }
     RowsFwdArgs ra = image_rows_args(g, t, d, S);
     for (int r = 0; r < F * g.rows; r++) rows_fwd_body(ctx, lds.data(), ra, r);
     return 0;
