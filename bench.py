@@ -140,10 +140,21 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # wait for all; a rank that fails would leave the others waiting in a collective for ever, so the
+    # first failure ends the ranks this function started (by their own PIDs)
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
     return rc
 
 
