@@ -183,3 +183,33 @@ def test_compute_fails_loudly_without_gpu(fftconv):
     assert e.value.status in (-6, -7)
     with pytest.raises(fftconv.FFTConvError):
         fftconv.Plan(8, 8, 1, 3, 3)
+
+
+def test_round2_entry_points_argument_errors_need_no_gpu(fftconv):
+    """pow2 sizing, the live-plan registry, plan options and the multi-device entry validate their
+    arguments before anything touches a device"""
+    import ctypes
+    lib = fftconv.load_library()
+    # computeFFTsize (src/cudaConvFFTData.h:67-94): align to 16, then to a power of two
+    assert [fftconv.fft_size_pow2(n) for n in (1, 16, 17, 64, 65, 286, 4222)] == [16, 16, 32, 64, 128, 512, 8192]
+    # no plan is live in a process that never created one: stray handles are not dereferenced
+    for stray in (0, 8, 0xDEADBEEF0):
+        assert lib.fftconv_plan_is_live(ctypes.c_void_p(stray)) == 0
+    assert lib.fftconv_plan_destroy(ctypes.c_void_p(0xDEADBEEF0)) != 0          # refused, not freed
+    # two-step convolve with a handle that is not a plan (src/cudaConvFFTData.cu:68)
+    rc = lib.fftconv_conv_fft_data(ctypes.c_void_p(0xDEADBEEF0), 0, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"Invalid input to MEX file" in lib.fftconv_last_error()
+    # multi-device entry: empty or NULL device list
+    h = ctypes.c_void_p(None)
+    assert lib.fftconv_multi_create(ctypes.byref(h), 8, 8, 1, 3, 3, None, 0, None) == -1 and not h.value
+    assert lib.fftconv_multi_size(None) == 0 and lib.fftconv_multi_destroy(None) == 0
+    # one-shot _ex: bad kernel location
+    data = np.zeros((8, 8, 1), np.float32)
+    rc = lib.fftconv_convolution_fft_ex(ctypes.c_void_p(data.ctypes.data), 8, 8, 1, 3, 3, 0, None, None, None, None, 7,
+                                        None, 0, 0, None, None, None, None)
+    assert rc == -1 and b"kernel location" in lib.fftconv_last_error()
+    # filter blocks of the in-library sharding == the Python orchestration's (cfg4: 128 per GPU of 8)
+    import importlib
+    mg = importlib.import_module("cuda-fft-convolution_amd.multi_gpu")
+    assert [mg.filter_shard(1024, r, 8) for r in range(8)] == [(128 * r, 128) for r in range(8)]
+    assert [mg.filter_shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
