@@ -260,8 +260,8 @@ def main():
         conv = mg.ImageStreamedConvolver(engine, nf)
 
         def run_steps(k):
-            for _ in range(k):
-                conv.run(imgs_h)
+            conv.run(imgs_h * k)      # k steps = the batch streamed k times back to back (the first H2D copy of a
+                                      # step rides behind the last image of the step before)
     else:
         conv = mg.FilterShardedConvolver(engine, dist if use_dist else None, rank, world, nf_total, src=0,
                                          depth=2 if overlap else 1, always_collective=args.force_collective)

@@ -213,3 +213,24 @@ def test_round2_entry_points_argument_errors_need_no_gpu(fftconv):
     mg = importlib.import_module("cuda-fft-convolution_amd.multi_gpu")
     assert [mg.filter_shard(1024, r, 8) for r in range(8)] == [(128 * r, 128) for r in range(8)]
     assert [mg.filter_shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/fftconv.h is the drop-in boundary: plain C99 (pointers and sizes, no C++ or HIP types),
+    and usable from C++ as well"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "fftconv.h"\n'
+                   'int use(void) {\n'
+                   '    fftconv_plan_options o = {0};\n'
+                   '    fftconv_plan *p = 0; fftconv_multi *m = 0; fftconv_plan_info info; fftconv_profile prof;\n'
+                   '    o.struct_size = sizeof o; (void)info; (void)prof; (void)p; (void)m;\n'
+                   '    return fftconv_fft_size16(17) + fftconv_fft_size_pow2(17) + (int)FFTCONV_AUTO + (int)FFTCONV_ERR_NO_IMAGE;\n'
+                   '}\n')
+    inc = os.path.join(util.ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)], check=True)
