@@ -40,3 +40,16 @@ def test_c_example_finds_the_planted_template(demo_binary, nplans):
     r = subprocess.run([demo_binary, str(nplans)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK") and "at (13, 4)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_python_port_of_the_reference_demo():
+    """examples/demo_cuda_convolution_fft.py: demoCudaConvolutionFFT.m step by step (set-up, conv2 and
+    fft2/ifft2 CPU references, the three-kernel call) with the figures' residuals as numbers"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("demo_ccf", os.path.join(util.ROOT, "examples", "demo_cuda_convolution_fft.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in (0, 1):
+        ok, res = mod.main(seed=seed)
+        assert ok, res
