@@ -3,8 +3,10 @@
 //
 //   cvcell = cudaConvFFTData(fftData, kernelCell[, threadSize])
 //
-// fftData is the handle returned by cudaFFTData (the reference takes the complex gpuArray,
-// src/cudaConvFFTData.cu:68-69,90-91); the image spectrum it stands for is reused for every call.
+// fftData is what cudaFFTData returned: the complex single gpuArray of the reference
+// ((FFT_H/2+1) x FFT_W x F, src/cudaConvFFTData.cu:68-69,90-98: FFT_H = (dim0 - 1) * 2, FFT_W = dim1) --
+// imported into a plan whose transform is that window (fftconv_plan_import_spectrum) -- or the
+// opaque uint64 handle of the alternative form, whose plan is reused for every call.
 #include <cstdint>
 #include <vector>
 
@@ -23,8 +25,7 @@
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const char* errId = FFTCONV_MEX_ERROR_ID;   // "cudaConvFFTData:InvalidInput" (src/cudaConvFFTData.cu:47)
     (void)nlhs;
-    if (nrhs < 2 || nrhs > 3 || mxGetClassID(prhs[0]) != mxUINT64_CLASS || mxGetNumberOfElements(prhs[0]) != 1)
-        mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");               // :68-69
+    if (nrhs < 2 || nrhs > 3) mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");   // :68-69
     const double* threads = nullptr;
     int nthreads = 0;
     if (nrhs > 2) {                                                                          // :71-72: checked by the library
@@ -32,11 +33,48 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         nthreads = (int)mxGetNumberOfElements(prhs[2]);
     }
     if (mxGetClassID(prhs[1]) != mxCELL_CLASS) mexErrMsgIdAndTxt(errId, "Kernel must be a cell array");   // :108-109
-    fftconv_plan* plan = reinterpret_cast<fftconv_plan*>((uintptr_t) * static_cast<const uint64_t*>(mxGetData(prhs[0])));
-    // a handle cudaFFTData released, one from before `clear mex`, or any stray uint64: refused, not dereferenced
-    if (!fftconv_plan_is_live(plan)) mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");
+    fftconv_plan* plan = nullptr;
+    bool own_plan = false;     // a plan made here around an imported gpuArray spectrum: destroyed before returning
+#if FFTCONV_MEX_GPU
+    if (mxIsGPUArray(prhs[0])) {                                                             // the reference's form (:68, :90-98)
+        mxInitGPU();
+        const mxGPUArray* fd = mxGPUCreateFromMxArray(prhs[0]);
+        const mwSize* fdim = mxGPUGetDimensions(fd);
+        const mwSize fnd = mxGPUGetNumberOfDimensions(fd);
+        const bool good = mxGPUGetClassID(fd) == mxSINGLE_CLASS && mxGPUGetComplexity(fd) == mxCOMPLEX && fnd >= 2 && fnd <= 3 && fdim[0] >= 2;
+        int rc = FFTCONV_ERR_INVALID_ARG;
+        if (good) {
+            const int FFT_H = ((int)fdim[0] - 1) * 2, FFT_W = (int)fdim[1], F = fnd == 3 ? (int)fdim[2] : 1;   // :92-98
+            fftconv_plan_options opts = {};
+            opts.struct_size = sizeof(opts);
+            opts.exact_window = 1;
+            // data size == window, kernel size 1: the window and the transform are FFT_H x FFT_W; kernels of any
+            // size up to the window then convolve circularly modulo it, as the reference's do
+            rc = fftconv_plan_create_ex(&plan, FFT_H, FFT_W, F, 1, 1, -1, nullptr, &opts);
+            if (rc == FFTCONV_OK) rc = fftconv_plan_import_spectrum(plan, static_cast<const float*>(mxGPUGetDataReadOnly(fd)), FFTCONV_DEVICE);
+            if (rc == FFTCONV_OK) rc = fftconv_plan_synchronize(plan);
+        }
+        mxGPUDestroyGPUArray(fd);
+        if (rc != FFTCONV_OK) {
+            if (plan) fftconv_plan_destroy(plan);
+            if (!good) mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");
+            mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
+        }
+        own_plan = true;
+    } else
+#endif
+    {
+        if (mxGetClassID(prhs[0]) != mxUINT64_CLASS || mxGetNumberOfElements(prhs[0]) != 1)
+            mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");           // :68-69
+        plan = reinterpret_cast<fftconv_plan*>((uintptr_t) * static_cast<const uint64_t*>(mxGetData(prhs[0])));
+        // a handle cudaFFTData released, one from before `clear mex`, or any stray uint64: refused, not dereferenced
+        if (!fftconv_plan_is_live(plan)) mexErrMsgIdAndTxt(errId, "The data must be FFT-ed real array in GPU");
+    }
     fftconv_plan_info info;
-    if (fftconv_plan_get_info(plan, &info) != FFTCONV_OK) mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
+    if (fftconv_plan_get_info(plan, &info) != FFTCONV_OK) {
+        if (own_plan) fftconv_plan_destroy(plan);
+        mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
+    }
     const int n = (int)mxGetNumberOfElements(prhs[1]);
     std::vector<const float*> kp(n);
     std::vector<int> kh(n), kw(n), kf(n);
@@ -49,6 +87,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 #endif
     auto bad_kernel = [&] {
         release_views();
+        if (own_plan) fftconv_plan_destroy(plan);
         mexErrMsgIdAndTxt(errId, "Kernels must be of type float and have features larger than 1");
     };
     for (int k = 0; k < n; k++) {
@@ -86,5 +125,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
     const int rc = fftconv_conv_fft_data(plan, n, kp.data(), kh.data(), kw.data(), kf.data(), threads, nthreads, out.data());
     release_views();
+    if (own_plan) fftconv_plan_destroy(plan);   // (the message of a failed call stays: destroy does not touch it on success)
     if (rc != FFTCONV_OK) mexErrMsgIdAndTxt(errId, "%s", fftconv_last_error());
 }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -19,11 +20,27 @@ struct mxArray_tag {
     // a gpuArray: the data lives in device memory (dev), MATLAB reports an opaque class for the mxArray itself
     bool on_gpu = false;
     mxClassID gpu_cls = mxUNKNOWN_CLASS;
+    mxComplexity gpu_cplx = mxREAL;
     void* dev = nullptr;
+    bool owns_dev = false;   // allocated by mxGPUCreateGPUArray (freed with the array)
 };
 struct mxGPUArray_tag {
     const mxArray* src;
+    mxArray* fresh;          // mxGPUCreateGPUArray: the array being built (handed over by mxGPUCreateMxArrayOnGPU)
+    bool handed_over;
 };
+// device memory for gpuArrays the gateways create: the process's own HIP runtime (already loaded by libfftconv.so)
+static void* dev_alloc(size_t bytes) {
+    typedef int (*malloc_t)(void**, size_t);
+    malloc_t f = (malloc_t)dlsym(RTLD_DEFAULT, "hipMalloc");
+    void* p = nullptr;
+    return (f && f(&p, bytes) == 0) ? p : nullptr;
+}
+static void dev_free(void* p) {
+    typedef int (*free_t)(void*);
+    free_t f = (free_t)dlsym(RTLD_DEFAULT, "hipFree");
+    if (f && p) f(p);
+}
 int g_live_gpu_views = 0;
 
 namespace {
@@ -47,12 +64,30 @@ const mwSize* mxGetDimensions(const mxArray* a) { return a->dims.data(); }
 mxClassID mxGetClassID(const mxArray* a) { return a->on_gpu ? mxUNKNOWN_CLASS : a->cls; }
 int mxInitGPU(void) { return MX_GPU_SUCCESS; }
 int mxIsGPUArray(const mxArray* a) { return a && a->on_gpu ? 1 : 0; }
-const mxGPUArray* mxGPUCreateFromMxArray(const mxArray* a) { g_live_gpu_views++; return new mxGPUArray_tag{a}; }
+const mxGPUArray* mxGPUCreateFromMxArray(const mxArray* a) { g_live_gpu_views++; return new mxGPUArray_tag{a, nullptr, false}; }
+mxComplexity mxGPUGetComplexity(const mxGPUArray* g) { return g->src->gpu_cplx; }
+mxGPUArray* mxGPUCreateGPUArray(mwSize ndim, const mwSize* dims, mxClassID cls, mxComplexity cplx, mxGPUInitialize) {
+    mxArray* a = new mxArray_tag();
+    a->dims.assign(dims, dims + ndim);
+    while (a->dims.size() < 2) a->dims.push_back(1);
+    a->on_gpu = true; a->gpu_cls = cls; a->gpu_cplx = cplx; a->owns_dev = true;
+    size_t n = 1;
+    for (mwSize d : a->dims) n *= d;
+    a->dev = dev_alloc(n * (cls == mxSINGLE_CLASS ? 4 : 8) * (cplx == mxCOMPLEX ? 2 : 1));
+    g_live_gpu_views++;
+    return new mxGPUArray_tag{a, a, false};
+}
+void* mxGPUGetData(mxGPUArray* g) { return g->src->dev; }
+mxArray* mxGPUCreateMxArrayOnGPU(const mxGPUArray* g) { const_cast<mxGPUArray*>(g)->handed_over = true; return g->fresh; }
 mxClassID mxGPUGetClassID(const mxGPUArray* g) { return g->src->gpu_cls; }
 mwSize mxGPUGetNumberOfDimensions(const mxGPUArray* g) { return g->src->dims.size(); }
 const mwSize* mxGPUGetDimensions(const mxGPUArray* g) { return g->src->dims.data(); }
 const void* mxGPUGetDataReadOnly(const mxGPUArray* g) { return g->src->dev; }
-void mxGPUDestroyGPUArray(const mxGPUArray* g) { g_live_gpu_views--; delete g; }
+void mxGPUDestroyGPUArray(const mxGPUArray* g) {
+    g_live_gpu_views--;
+    if (g->fresh && !g->handed_over) mxDestroyArray(g->fresh);   // never returned to MATLAB: goes with its view
+    delete g;
+}
 size_t mxGetNumberOfElements(const mxArray* a) { return count(a); }
 void* mxGetData(const mxArray* a) { return const_cast<unsigned char*>(a->data.data()); }
 double mxGetScalar(const mxArray* a) {
@@ -86,6 +121,7 @@ mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity c
 }
 void mxDestroyArray(mxArray* a) {
     if (!a) return;
+    if (a->owns_dev) dev_free(a->dev);
     for (mxArray* c : a->cells) mxDestroyArray(c);
     delete a;
 }
@@ -113,8 +149,11 @@ mxArray* mock_new_numeric(int cls, int ndim, const uint64_t* dims, const void* d
     return a;
 }
 // a gpuArray of class `cls` whose elements live at device pointer `dev` (owned by the test)
-mxArray* mock_new_gpu(int cls, int ndim, const uint64_t* dims, void* dev) {
+mxArray* mock_new_gpu_ex(int cls, int ndim, const uint64_t* dims, void* dev, int is_complex);
+mxArray* mock_new_gpu(int cls, int ndim, const uint64_t* dims, void* dev) { return mock_new_gpu_ex(cls, ndim, dims, dev, 0); }
+mxArray* mock_new_gpu_ex(int cls, int ndim, const uint64_t* dims, void* dev, int is_complex) {
     mxArray* a = new mxArray_tag();
+    a->gpu_cplx = is_complex ? mxCOMPLEX : mxREAL;
     a->dims.assign(dims, dims + ndim);
     while (a->dims.size() < 2) a->dims.push_back(1);
     a->on_gpu = true;
@@ -122,7 +161,10 @@ mxArray* mock_new_gpu(int cls, int ndim, const uint64_t* dims, void* dev) {
     a->dev = dev;
     return a;
 }
-int mock_live_gpu_views(void) { return g_live_gpu_views; }   // mxGPUCreateFromMxArray not yet destroyed
+int mock_live_gpu_views(void) { return g_live_gpu_views; }
+int mock_is_gpu(const mxArray* a) { return a->on_gpu ? 1 : 0; }
+int mock_gpu_is_complex(const mxArray* a) { return a->gpu_cplx == mxCOMPLEX ? 1 : 0; }
+void* mock_gpu_ptr(const mxArray* a) { return a->dev; }   // mxGPUCreateFromMxArray not yet destroyed
 mxArray* mock_new_cell(int n) { return mxCreateCellMatrix(1, n); }
 void mock_set_cell(mxArray* c, int i, mxArray* v) { mxSetCell(c, i, v); }
 mxArray* mock_get_cell(mxArray* c, int i) { return mxGetCell(c, i); }

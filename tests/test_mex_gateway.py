@@ -29,6 +29,12 @@ class Mex:
         self.rt.mock_new_cell.restype = vp
         self.rt.mock_new_gpu.restype = vp
         self.rt.mock_new_gpu.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
+        self.rt.mock_new_gpu_ex.restype = vp
+        self.rt.mock_new_gpu_ex.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int]
+        self.rt.mock_is_gpu.argtypes = [vp]
+        self.rt.mock_gpu_is_complex.argtypes = [vp]
+        self.rt.mock_gpu_ptr.restype = vp
+        self.rt.mock_gpu_ptr.argtypes = [vp]
         self.rt.mock_set_cell.argtypes = [vp, ctypes.c_int, vp]
         self.rt.mock_get_cell.restype = vp
         self.rt.mock_get_cell.argtypes = [vp, ctypes.c_int]
@@ -57,6 +63,16 @@ class Mex:
         """a gpuArray of MATLAB shape `shape` whose elements are the torch device tensor's memory"""
         dims = (ctypes.c_uint64 * len(shape))(*shape)
         return self.rt.mock_new_gpu(cls, len(shape), dims, ctypes.c_void_p(tensor.data_ptr()))
+
+    def gpu_to_numpy_complex(self, m):
+        """a complex single gpuArray the gateway created -> numpy complex64 in MATLAB (column-major) shape"""
+        assert self.rt.mock_is_gpu(m) and self.rt.mock_gpu_is_complex(m)
+        shape = tuple(self.rt.mock_dim(m, i) for i in range(self.rt.mock_ndim(m)))
+        out = np.empty(int(np.prod(shape)), dtype=np.complex64)
+        hip = ctypes.CDLL(None)                      # the process's HIP runtime (loaded with libfftconv.so)
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(self.rt.mock_gpu_ptr(m)), out.nbytes, 2) == 0
+        return out.reshape(shape, order="F")
 
     def scalar(self, v):
         return self.numeric(np.array([[float(v)]], dtype=np.float64))
@@ -171,7 +187,7 @@ def test_one_shot_gateway_matches_oracle(mex, oracle):
 @pytest.mark.gpu
 def test_two_step_gateways_match_one_shot(mex, oracle):
     data, ks = demo_inputs(9)
-    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4), mex.scalar(0), mex.scalar(1)])   # handle form
     assert not raised, out
     handle = out[0]
     assert mex.to_numpy(handle).dtype == np.uint64
@@ -189,7 +205,7 @@ def test_two_step_gateways_match_one_shot(mex, oracle):
     assert not raised
     raised, _ = mex.call("cudaFFTData", [handle], nlhs=0)
     assert raised
-    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4), mex.scalar(0), mex.scalar(1)])
     assert not raised
     mex.rt.mock_run_at_exit()
 
@@ -231,8 +247,8 @@ def test_gpuarray_kernels_and_released_handles(mex, oracle):
     raised, (eid, msg) = mex.call("cudaConvolutionFFT", [mex.numeric(data), mex.scalar(10), mex.scalar(4), bad])
     assert raised and eid == ERR_ID and msg.startswith("Kernels must be of type float")
     assert mex.rt.mock_live_gpu_views() == 0
-    # two-step gateway with gpuArray kernels
-    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4)])
+    # two-step gateway with gpuArray kernels (handle form of fftData)
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(10), mex.scalar(4), mex.scalar(0), mex.scalar(1)])
     assert not raised, out
     handle = out[0]
     raised, out = mex.call("cudaConvFFTData", [handle, mex.cell([mex.gpu_array(dev[0], (10, 4, 5)), mex.numeric(ks[1]), mex.gpu_array(dev[2], (10, 4, 5))])])
@@ -244,3 +260,41 @@ def test_gpuarray_kernels_and_released_handles(mex, oracle):
     assert not raised
     raised, (eid, msg) = mex.call("cudaConvFFTData", [handle, mex.cell([mex.numeric(k) for k in ks])])
     assert raised and msg == "The data must be FFT-ed real array in GPU"   # ... and the stale handle is refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4), (256, 256, 1, 31, 31), (200, 150, 2, 9, 12)])
+def test_two_step_gateways_speak_the_reference_gpuarray_protocol(mex, oracle, shape):
+    """fftData = cudaFFTData(data, kH, kW) is a complex single gpuArray of (FFT_H/2+1) x FFT_W x F holding
+    cuFFT's R2C output (src/cudaFFTData.cu:90-103,150) == numpy.fft.rfft2 of the zero-padded planes;
+    cudaConvFFTData(fftData, kernelCell) recovers FFT_H = (dim0-1)*2, FFT_W = dim1 from it
+    (src/cudaConvFFTData.cu:90-98) and convolves -- also after the spectrum was edited in between"""
+    H, W, F, kh, kw = shape
+    rng = np.random.default_rng(sum(shape))
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(2)] + [rng.random((max(1, kh - 2), kw, F), dtype=np.float32)]
+    fh, fw = util.ceil16(H + kh - 1), util.ceil16(W + kw - 1)
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(kh), mex.scalar(kw)])
+    assert not raised, out
+    fft_data = out[0]
+    spec = mex.gpu_to_numpy_complex(fft_data)
+    assert spec.shape == (fh // 2 + 1, fw, F)
+    padded = np.zeros((fh, fw, F))
+    padded[:H, :W, :] = data
+    want = np.fft.fft2(padded, axes=(0, 1))[:fh // 2 + 1, :, :]          # rows 1 .. FFT_H/2+1 of fft2(data(:,:,f), FFT_H, FFT_W)
+    assert np.abs(spec - want).max() / np.abs(want).max() < 1e-5
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    for rep in range(2):
+        raised, out = mex.call("cudaConvFFTData", [fft_data, mex.cell([mex.numeric(k) for k in ks]),
+                                                   mex.numeric(np.array([[8.0, 8.0, 8.0, 16.0]]))])
+        assert not raised, out
+        for g, r in zip(mex.cell_to_list(out[0], len(ks)), ref):
+            assert g.shape == (fh, fw) and util.rel_err(g, r) < 1e-5
+    assert mex.rt.mock_live_gpu_views() == 0
+    # a real (not complex) gpuArray is not FFT-ed data
+    torch = pytest.importorskip("torch")
+    junk = torch.zeros(fh // 2 + 1, fw, F, dtype=torch.float32, device="cuda")
+    raised, (eid, msg) = mex.call("cudaConvFFTData", [mex.gpu_array(junk, (fh // 2 + 1, fw, F)), mex.cell([mex.numeric(ks[0])])])
+    assert raised and eid == ERR_ID and msg == "The data must be FFT-ed real array in GPU"
+    assert mex.rt.mock_live_gpu_views() == 0
+    mex.rt.mock_free(fft_data)
