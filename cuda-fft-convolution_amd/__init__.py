@@ -87,7 +87,8 @@ EXPORTED_SYMBOLS = (
     "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_prepare_kernels_packed",
     "fftconv_plan_synchronize", "fftconv_plan_set_stream",
     "fftconv_plan_set_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
-    "fftconv_multi_create", "fftconv_multi_destroy", "fftconv_multi_set_image", "fftconv_multi_convolve",
+    "fftconv_multi_create", "fftconv_multi_destroy", "fftconv_multi_set_image", "fftconv_multi_import_spectrum",
+    "fftconv_multi_convolve",
     "fftconv_multi_shard", "fftconv_multi_size", "fftconv_multi_plan", "fftconv_convolution_fft_multi",
 )
 
@@ -157,6 +158,7 @@ def load_library():
     lib.fftconv_multi_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, pi, ci, vp]
     lib.fftconv_multi_destroy.argtypes = [vp]
     lib.fftconv_multi_set_image.argtypes = [vp, vp, ci]
+    lib.fftconv_multi_import_spectrum.argtypes = [vp, vp, ci]
     lib.fftconv_multi_convolve.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci]
     lib.fftconv_multi_shard.argtypes = [vp, ci, ci, pi, pi]
     lib.fftconv_multi_size.argtypes = [vp]

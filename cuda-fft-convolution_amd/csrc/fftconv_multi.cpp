@@ -112,19 +112,17 @@ int fftconv_multi_shard(const fftconv_multi* multi, int n_kernel, int index, int
     return 0;
 }
 
-int fftconv_multi_set_image(fftconv_multi* multi, const float* data, int location) {
-    if (!multi || !data) return api_fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
-    fftconv_multi* m = multi;
-    m->have_image = false;
-    if (int rc = fftconv_plan_set_image(m->plan[0], data, location)) return rc;
+namespace {
+// the spectrum of plan[0] (complete on stream[0]) to every other device: GPU 0 -> GPU g (the reference's
+// cudaMemcpyPeerAsync, src/cudaConvFFTDataStreams.cu:282-287), each copy on the destination's stream
+// behind an event, so the next convolve on that stream is ordered behind its copy
+int distribute_spectrum(fftconv_multi* m) {
     void* src = nullptr;
     size_t bytes = 0;
     if (int rc = fftconv_plan_spectrum(m->plan[0], &src, &bytes)) return rc;
     hipError_t e = hipSetDevice(m->dev[0]);
     if (e == hipSuccess) e = hipEventRecord(m->spectrum_ready, m->stream[0]);
     if (e != hipSuccess) return api_fail(FFTCONV_ERR_HIP, "event record failed: %s", hipGetErrorString(e));
-    // GPU 0 -> GPU g (the reference's cudaMemcpyPeerAsync, src/cudaConvFFTDataStreams.cu:282-287), each
-    // copy on the destination's stream: the next convolve on that stream is ordered behind it
     for (size_t g = 1; g < m->plan.size(); g++) {
         void* dst = nullptr;
         if (int rc = fftconv_plan_spectrum(m->plan[g], &dst, nullptr)) return rc;
@@ -138,6 +136,21 @@ int fftconv_multi_set_image(fftconv_multi* multi, const float* data, int locatio
     }
     m->have_image = true;
     return 0;
+}
+}  // namespace
+
+int fftconv_multi_set_image(fftconv_multi* multi, const float* data, int location) {
+    if (!multi || !data) return api_fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
+    multi->have_image = false;
+    if (int rc = fftconv_plan_set_image(multi->plan[0], data, location)) return rc;
+    return distribute_spectrum(multi);
+}
+
+int fftconv_multi_import_spectrum(fftconv_multi* multi, const float* spectrum, int location) {
+    if (!multi || !spectrum) return api_fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
+    multi->have_image = false;
+    if (int rc = fftconv_plan_import_spectrum(multi->plan[0], spectrum, location)) return rc;
+    return distribute_spectrum(multi);
 }
 
 int fftconv_multi_convolve(fftconv_multi* multi, int n_kernel, const float* const* kernels, const int* kernel_h,

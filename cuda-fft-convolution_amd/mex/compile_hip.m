@@ -10,7 +10,7 @@ if ~exist(fullfile(pkg, 'libfftconv.so'), 'file')
   assert(system(['make -C ' fullfile(pkg, 'csrc')]) == 0, 'building libfftconv.so failed');
 end
 if ~exist(fullfile(repo, 'bin'), 'dir'), mkdir(fullfile(repo, 'bin')); end
-names = {'cudaFFTData', 'cudaConvFFTData', 'cudaConvolutionFFT'};
+names = {'cudaFFTData', 'cudaConvFFTData', 'cudaConvolutionFFT', 'cudaConvFFTDataStreams'};   % the last needs the GPU header
 % gpuArray kernels (src/cudaConvolutionFFT.cu:224-238): the gateways compile that branch when
 % gpu/mxGPUArray.h is found; it lives where cuda_compile.m:48-52 takes it from and needs libmwgpu (:58)
 gpuinc = fullfile(matlabroot, 'toolbox', 'distcomp', 'gpu', 'extern', 'include');

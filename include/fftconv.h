@@ -303,6 +303,10 @@ int fftconv_multi_destroy(fftconv_multi *multi);
 /* padData + cufftExecR2C of the image on devices[0] (src/cudaConvolutionFFT.cu:144-169), then the
  * peer copies.  location FFTCONV_HOST, or FFTCONV_DEVICE for memory of devices[0]. */
 int fftconv_multi_set_image(fftconv_multi *multi, const float *data, int location);
+/* Instead of an image: its spectrum in the reference's order (fftconv_plan_import_spectrum; the handle
+ * must have been created with fftconv_plan_options.exact_window = 1) -- what the reference's
+ * multi-GPU MEX takes as its first argument (src/cudaConvFFTDataStreams.cu:160-187). */
+int fftconv_multi_import_spectrum(fftconv_multi *multi, const float *spectrum, int location);
 /* The per-kernel loop over all devices.  FFTCONV_HOST kernels / outputs are plain host arrays;
  * FFTCONV_DEVICE pointers must live on the device that owns the kernel (fftconv_multi_shard). */
 int fftconv_multi_convolve(fftconv_multi *multi, int n_kernel, const float *const *kernels,

@@ -49,7 +49,7 @@ class Mex:
         self.rt.mock_error_msg.restype = ctypes.c_char_p
         self.rt.mock_call.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
         self.gw = {n: ctypes.CDLL(os.path.join(MOCK_DIR, n + ".mexmock.so"))
-                   for n in ("cudaConvolutionFFT", "cudaFFTData", "cudaConvFFTData")}
+                   for n in ("cudaConvolutionFFT", "cudaFFTData", "cudaConvFFTData", "cudaConvFFTDataStreams")}
 
     # -- MATLAB values
     def numeric(self, a):
@@ -296,5 +296,41 @@ def test_two_step_gateways_speak_the_reference_gpuarray_protocol(mex, oracle, sh
     junk = torch.zeros(fh // 2 + 1, fw, F, dtype=torch.float32, device="cuda")
     raised, (eid, msg) = mex.call("cudaConvFFTData", [mex.gpu_array(junk, (fh // 2 + 1, fw, F)), mex.cell([mex.numeric(ks[0])])])
     assert raised and eid == ERR_ID and msg == "The data must be FFT-ed real array in GPU"
+    assert mex.rt.mock_live_gpu_views() == 0
+    mex.rt.mock_free(fft_data)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_streams_gateway(mex, oracle):
+    """cudaConvFFTDataStreams(fftData, kernelCell[, threadSize][, gpuIds]): the reference's multi-GPU MEX
+    (src/cudaConvFFTDataStreams.cu) over fftconv_multi_* -- the complex gpuArray spectrum in, kernels dealt over
+    the listed devices (here the test GPU once, twice, three times), host maps out"""
+    H, W, F, kh, kw = 120, 90, 3, 11, 8
+    rng = np.random.default_rng(5)
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(5)]
+    ks[3] = rng.random((kh - 4, kw - 1, F), dtype=np.float32)
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(kh), mex.scalar(kw)])
+    assert not raised, out
+    fft_data = out[0]
+    kc = lambda: mex.cell([mex.numeric(k) for k in ks])
+    for extra in ([], [mex.numeric(np.array([[8.0, 8.0, 8.0, 16.0]]))],
+                  [mex.numeric(np.zeros((0, 0))), mex.numeric(np.array([[0.0, 0.0]]))],
+                  [mex.numeric(np.array([[8.0, 8.0, 8.0, 16.0]])), mex.numeric(np.array([[0.0, 0.0, 0.0]]))]):
+        raised, out = mex.call("cudaConvFFTDataStreams", [fft_data, kc()] + extra)
+        assert not raised, out
+        for g, r in zip(mex.cell_to_list(out[0], len(ks)), ref):
+            assert util.rel_err(g, r) < 1e-5
+        assert mex.rt.mock_live_gpu_views() == 0
+    # argument errors of the reference (:160-164,196-197)
+    raised, (eid, msg) = mex.call("cudaConvFFTDataStreams", [mex.numeric(data), kc()])
+    assert raised and eid == "parallel:gpu:mexGPUExample:InvalidInput" and msg == "The data must be FFT-ed real array in GPU"
+    raised, (eid, msg) = mex.call("cudaConvFFTDataStreams", [fft_data, kc(), mex.numeric(np.array([[8.0, 8.0]]))])
+    assert raised and msg.startswith("CUDA Thread Size must be 4 integers")
+    raised, (eid, msg) = mex.call("cudaConvFFTDataStreams", [fft_data, mex.numeric(ks[0])])
+    assert raised and msg == "Kernel must be a cell array"
+    raised, (eid, msg) = mex.call("cudaConvFFTDataStreams", [fft_data, kc(), mex.numeric(np.zeros((0, 0))), mex.numeric(np.array([[0.0, 42.0]]))])
+    assert raised and "out of range" in msg
     assert mex.rt.mock_live_gpu_views() == 0
     mex.rt.mock_free(fft_data)
