@@ -303,6 +303,8 @@ struct fftconv_plan {
     long opt_host_slots = 0;       // ring chunks (0 = auto)
     HostRing* ring = nullptr;      // created on the first host-output convolve
     bool profile = false;
+    unsigned profile_mask = ~0u;   // which kinds (bit = PK_* index) are timed while `profile` is on
+    bool prof_open = false;        // the last prof_begin recorded a start event
     // kernel column spectra of the first chunk already in A (fftconv_plan_prepare_kernels_packed)
     struct { const float* dk = nullptr; int n = 0, kh = 0, kw = 0; } prepared;
     std::vector<EventPair> pending;
@@ -315,7 +317,8 @@ struct fftconv_plan {
     size_t rows_lds() const { return (size_t)g.Lw * sizeof(c32) * (g.F > 1 ? 2 : 1); }
 
     int prof_begin(int kind, long units) {
-        if (!profile) return 0;
+        prof_open = profile && ((profile_mask >> kind) & 1u);
+        if (!prof_open) return 0;
         EventPair ep;
         if (!pool.empty()) {
             ep = pool.back();
@@ -331,7 +334,8 @@ struct fftconv_plan {
         return 0;
     }
     int prof_end() {
-        if (!profile) return 0;
+        if (!prof_open) return 0;
+        prof_open = false;
         HIP_TRY(hipEventRecord(pending.back().stop, stream));
         return 0;
     }
@@ -1052,10 +1056,8 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
 
 int fftconv_plan_set_stream(fftconv_plan* plan, void* hip_stream) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
-    if (plan->profile && !plan->pending.empty()) {
-        if (int rc = use_device(plan)) return rc;
-        if (int rc = plan->prof_collect()) return rc;   // events recorded on the old stream
-    }
+    // (profile events already recorded stay valid: they are read later by fftconv_plan_get_profile,
+    //  whichever stream they were recorded on -- collecting them here would block the host)
     plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
     plan->prepared.dk = nullptr;
     return 0;
@@ -1072,6 +1074,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "profile_kinds")) { plan->profile_mask = value <= 0 ? ~0u : (unsigned)value; return 0; }
     if (!strcmp(name, "rows_group")) { plan->g.rows_group = value <= 0 ? -1 : (int)value; return 0; }
 #if FC_ROWS_TIMELINE || FC_COLS_TIMELINE
     // diagnostic builds only (tools/rows_timeline.py, tools/cols_timeline.py): device buffer one workgroup stamps
