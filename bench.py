@@ -52,6 +52,7 @@ CONFIGS = {
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 CHECK_TOL_ORACLE = 1e-4   # north_star parity bar (max|out - ref| / max|ref| per map)
 CHECK_TOL_CHECKSUM = 1e-5  # sum(map) vs sum(image) * sum(kernel), relative
+CLOCK_WARM_S = 0.08       # untimed load before the timed region (the clock ramp after idle is ~40 ms)
 
 
 def ceil16(n):
@@ -168,6 +169,7 @@ def main():
     ap.add_argument("--filters", type=int, default=0, help="filters of the whole job (0 = the config's); sharded over the ranks")
     ap.add_argument("--weak", action="store_true", help="--filters (or the config's count) is per GPU: weak scaling")
     ap.add_argument("--batch-maps", type=int, default=0)
+    ap.add_argument("--kernel-chunk-mb", type=int, default=0, help="budget of the kernels' column-spectrum chunk (0 = the library's default; A/B)")
     ap.add_argument("--rows-group", type=int, default=0, help="maps per workgroup of the spectral-row kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
@@ -185,6 +187,8 @@ def main():
                     help="one spectrum buffer: image transform + broadcast of a step not overlapped with the previous step's maps (A/B)")
     ap.add_argument("--overlap", action="store_true",
                     help="single GPU: two spectrum buffers as at N > 1 -- the image transform of step k + 1 on a side stream beside the maps of step k (A/B)")
+    ap.add_argument("--no-clock-warm", action="store_true",
+                    help="exactly W warm-up steps even when they are shorter than the GPU's clock ramp (A/B)")
     ap.add_argument("--no-live-profile", action="store_true",
                     help="do not time the dominant kernel inside the timed region (roofline from the separate pass only; A/B)")
     ap.add_argument("--force-collective", action="store_true",
@@ -247,6 +251,8 @@ def main():
         plan.set_option("batch_maps", args.batch_maps)
     if args.rows_group:
         plan.set_option("rows_group", args.rows_group)
+    if args.kernel_chunk_mb:
+        plan.set_option("kernel_chunk_mb", args.kernel_chunk_mb)
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
     # the next image's H2D copy (streamed mode)
     overlap = streamed or ((use_dist or args.overlap) and not args.no_overlap)
@@ -279,6 +285,26 @@ def main():
 
     run_steps(args.warmup)
     barrier()
+    # The GPU needs ~40 ms of continuous load to settle its clocks after any idle gap (tools/clock_ramp.py,
+    # profiles/r02w_clock_ramp.txt: the first ten 3-ms steps run up to 28 % slow).  Where the W warm-up steps are
+    # shorter than that (small configurations, small W) more untimed steps follow, the same number on every rank.
+    clock_warm_steps = 0
+    if not args.no_clock_warm:
+        t1 = time.perf_counter()
+        run_steps(1)
+        torch.cuda.synchronize(dev)
+        est = time.perf_counter() - t1
+        if use_dist:
+            te = torch.tensor([est], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            est = float(te.item())
+        if (args.warmup + 1) * est < CLOCK_WARM_S:
+            clock_warm_steps = min(3000, int(CLOCK_WARM_S / max(est, 1e-6)) + 1)
+            for c0 in range(0, clock_warm_steps, 64):     # in short bursts: never a deep queue behind the host
+                run_steps(min(64, clock_warm_steps - c0))
+                torch.cuda.synchronize(dev)
+        clock_warm_steps += 1
+        barrier()
     graph = None
     if args.graph:
         if use_dist or streamed:
@@ -297,12 +323,16 @@ def main():
         for _ in range(max(1, args.warmup)):
             graph.replay()
         barrier()
-    # the dominant kernel (the output columns) is timed by HIP events INSIDE the timed region, on the plan's
-    # stream: two event records per launch of that one kernel (the others stay unobserved here; their
-    # breakdown comes from the separate pass below)
-    live_profile = graph is None and not args.no_live_profile
+    # the two hot kernels (spectral rows, output columns) are timed by HIP events INSIDE the timed region, on
+    # the plan's stream: two event records per launch of those kernels (the one-off passes stay unobserved
+    # here; their figures come from the separate pass below)
+    # ... where a hot launch is long enough not to feel them: a pair costs ~5-20 us of stream time, which
+    # is 5 % of a cfg5 launch and most of a cfg1 step (profiles/r02w_live_event_cost.txt), so launches under
+    # 5e8 padded pixels (< ~0.7 ms) are timed in the separate pass only
+    per_launch_px = min(args.batch_maps or 64, max(nf, 1)) * P
+    live_profile = graph is None and not args.no_live_profile and per_launch_px >= 5e8
     if live_profile:
-        plan.set_option("profile_kinds", 1 << 2)       # index 2 of fftconv_profile: cols_c2r
+        plan.set_option("profile_kinds", (1 << 1) | (1 << 2))   # indices of fftconv_profile: spectral_rows, cols_c2r
         plan.set_option("profile", 1)
         plan.profile(reset=True)
     t0 = time.perf_counter()
@@ -315,7 +345,7 @@ def main():
     dt = time.perf_counter() - t0
     live = None
     if live_profile:
-        live = plan.profile(reset=True)["cols_c2r"]
+        live = plan.profile(reset=True)
         plan.set_option("profile", 0)
         plan.set_option("profile_kinds", 0)
     if use_dist:
@@ -339,11 +369,14 @@ def main():
     if args.check:
         chk_img_h = np.asfortranarray(np.transpose(chk_img.cpu().numpy(), (2, 1, 0)))
 
-    # per-kernel HIP-event timing of the same steps, on the plan's stream (separate pass so the
-    # event records do not sit inside the headline timing)
+    # HIP-event timing of EVERY kernel of the same steps, on the plan's stream, in a separate pass (so that the
+    # one-off passes carry no event records inside the headline timing).  The check above left the GPU idle
+    # and the clocks take ~40 ms of load to settle again (tools/clock_ramp.py): a few unobserved steps first
+    n_sep = max(1, min(args.steps, 3))
+    run_steps(max(1, min(200, int(0.06 / max(dt / args.steps, 1e-6)) + 1)))   # same count on every rank (dt is the max over ranks)
     plan.set_option("profile", 1)
     plan.profile(reset=True)
-    run_steps(max(1, min(args.steps, 3)))
+    run_steps(n_sep)
     torch.cuda.synchronize(dev)
     prof = plan.profile(reset=True)
     plan.set_option("profile", 0)
@@ -382,13 +415,16 @@ def main():
                 units = p["units"] / p["launches"]
                 per[name] = {"avg_ms": avg_ms, "units_per_launch": units,
                              "gbps": ab[name] * units / (avg_ms * 1e-3) / 1e9}
-        dom = max(per, key=lambda k: prof[k]["ms"]) if per else None
-        if dom == "cols_c2r" and live and live["launches"]:
-            # the roofline figure uses the launches of the timed region itself
-            avg_ms = live["ms"] / live["launches"]
-            units = live["units"] / live["launches"]
-            per[dom] = {"avg_ms": avg_ms, "units_per_launch": units, "gbps": ab[dom] * units / (avg_ms * 1e-3) / 1e9,
-                        "separate_pass_avg_ms": per[dom]["avg_ms"], "timed_in": "the timed region (%d launches)" % live["launches"]}
+        for name in list(per):
+            lv = live.get(name) if live else None
+            if lv and lv["launches"]:
+                # the figures of the hot kernels (and so the roofline) use the launches of the timed region itself
+                avg_ms = lv["ms"] / lv["launches"]
+                units = lv["units"] / lv["launches"]
+                per[name] = {"avg_ms": avg_ms, "units_per_launch": units, "gbps": ab[name] * units / (avg_ms * 1e-3) / 1e9,
+                             "separate_pass_avg_ms": per[name]["avg_ms"],
+                             "timed_in": "the timed region (%d launches)" % lv["launches"]}
+        dom = max(per, key=lambda k: per[k]["avg_ms"] / per[k]["units_per_launch"]) if per else None
         traffic = None
         traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -423,7 +459,7 @@ def main():
                        "transform": [info.transform_h, info.transform_w],
                        "filters_total": nf_total,
                        "filters_per_gpu": nf if streamed else -(-nf_total // world),
-                       "hip_graph_replay": bool(args.graph),
+                       "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps,
                        "images_per_step": args.images if streamed else 1,
                        "parallelism": ("images x%d, streamed H2D" % world) if streamed else
                                       ("filters x%d + 1 bcast per step" % world if world > 1 else "single GPU")},

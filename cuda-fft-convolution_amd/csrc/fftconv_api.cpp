@@ -297,6 +297,7 @@ struct fftconv_plan {
     DevBuf<c32> NS;                       // its device staging for host callers
     int num_cus = 256;
     long opt_batch_maps = 0;
+    long opt_kernel_chunk_mb = 0;
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
     long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
@@ -405,11 +406,17 @@ BatchSizes batch_sizes(const fftconv_plan* p, int n, int kw) {
     b.nbY = (int)p->opt_batch_maps;
     if (b.nbY <= 0) b.nbY = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)5120 << 20) / y_bytes));
     b.nbY = std::min(b.nbY, n);
-    // kernels per column-spectrum chunk: a multiple of nbY within 512 MiB
-    const size_t a_budget = (size_t)512 << 20;
-    b.nbA = (int)std::max<size_t>(1, a_budget / (b.per_a * sizeof(c32)));
-    b.nbA = std::max(b.nbY, b.nbA / b.nbY * b.nbY);
-    b.nbA = std::min(b.nbA, (n + b.nbY - 1) / b.nbY * b.nbY);
+    // kernels per column-spectrum chunk.  auto: one chunk per launch of the row kernel -- the chunk (138 MB for
+    // 64 kernels at cfg3) is then still in the 256-MB Infinity Cache when the row kernel prefetches its rows
+    // (row kernel 22.55 -> 22.08 us per map against 192-kernel chunks, profiles/r02w_kernel_chunk_ab.txt);
+    // option kernel_chunk_mb > 0: as many launches' worth as fit that budget
+    b.nbA = b.nbY;
+    if (p->opt_kernel_chunk_mb > 0) {
+        const size_t a_budget = (size_t)p->opt_kernel_chunk_mb << 20;
+        b.nbA = (int)std::max<size_t>(1, a_budget / (b.per_a * sizeof(c32)));
+        b.nbA = std::max(b.nbY, b.nbA / b.nbY * b.nbY);
+        b.nbA = std::min(b.nbA, (n + b.nbY - 1) / b.nbY * b.nbY);
+    }
     return b;
 }
 
@@ -1072,6 +1079,7 @@ int fftconv_plan_synchronize(fftconv_plan* plan) {
 
 int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
     if (!strcmp(name, "profile_kinds")) { plan->profile_mask = value <= 0 ? ~0u : (unsigned)value; return 0; }

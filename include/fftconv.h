@@ -237,10 +237,12 @@ int fftconv_plan_set_stream(fftconv_plan *plan, void *hip_stream);
 int fftconv_plan_synchronize(fftconv_plan *plan);
 
 /* Options: "batch_maps" (kernels per spectral/output launch, 0 = auto),
+ *          "kernel_chunk_mb" (0 = auto: the kernels' column spectra are produced one launch's worth at a
+ *             time, right before the row kernel reads them; > 0: as many launches' worth as fit that many MiB),
  *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
  *          "profile" (1: time every kernel launch with HIP events on the plan's stream),
  *          "profile_kinds" (bit mask over the indices of fftconv_profile: only those kinds are timed
- *             while "profile" is on, 0 = all -- lets a caller time ONE kernel inside its own timed
+ *             while "profile" is on, 0 = all -- lets a caller time the hot kernels inside its own timed
  *             region at the cost of two event records per launch),
  *          "host_stream" (how maps reach HOST output buffers -- the reference's blocking
  *             cudaMemcpy per map, src/cudaConvolutionFFT.cu:284-286: 0 = blocking copies after each

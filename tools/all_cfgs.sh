@@ -1,5 +1,5 @@
 # one bench line per BASELINE config (device-resident timing), defaults
-for c in cfg1 cfg2 cfg3 "cfg4 --filters 128" cfg5; do python bench.py --config $c --no-cpu-baseline --steps ${STEPS:-10} --warmup 3 --check 2>/dev/null | python -c "
+for c in cfg1 cfg2 cfg3 "cfg4 --filters 128" cfg5; do python bench.py --config $c --no-cpu-baseline --steps ${STEPS:-10} --warmup 5 --check 2>/dev/null | python -c "
 import sys,json
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=j['kernels']
