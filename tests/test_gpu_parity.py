@@ -168,8 +168,11 @@ def test_device_resident_packed_path(fc, oracle):
     with torch.cuda.stream(s):
         with fc.Plan(H, W, F, kh, kw, 0, s.cuda_stream) as p:
             out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
-            for batch in (0, 1, 3):
+            # maps per launch x budget of the kernels' column-spectrum chunk (0 = one launch's worth per chunk;
+            # 1 MiB and 512 MiB: chunks spanning one / several launches)
+            for batch, chunk_mb in ((0, 0), (1, 0), (3, 0), (3, 1), (2, 512), (0, 1)):
                 p.set_option("batch_maps", batch)
+                p.set_option("kernel_chunk_mb", chunk_mb)
                 out.fill_(float("nan"))
                 p.set_image_device(img_d.data_ptr())
                 p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
@@ -198,6 +201,15 @@ def test_prepare_kernels_split(fc, oracle):
         p.synchronize()
         for j in range(n):
             assert util.rel_err(out[j].cpu().numpy().T, ref[j]) < TIGHT
+        # several column-spectrum chunks per call (2 maps per launch): only the first one is prepared ahead
+        p.set_option("batch_maps", 2)
+        out.fill_(float("nan"))
+        p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+        for j in range(n):
+            assert util.rel_err(out[j].cpu().numpy().T, ref[j]) < TIGHT
+        p.set_option("batch_maps", 0)
         p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
         p.convolve_packed_device(n, k2_d.data_ptr(), kh, kw, out.data_ptr())   # different kernels: recomputed
         p.synchronize()
