@@ -1,4 +1,4 @@
-// fast_rows_multi.hpp -- spectral-row kernel, several maps per workgroup (F = 1).
+// fast_rows_multi.hpp -- spectral-row kernel, several maps per workgroup.
 //
 // fast_rows_body (fast_rows.hpp) gives every (row group, kernel) pair a workgroup of its own:
 // each one pays the launch, the stage-2 twiddle fill, the exposed latency of its kernel-row load
@@ -12,6 +12,12 @@
 //   * the stores of map m drain while map m + 1 is transformed.
 // The phases are those of fast_rows_body, unchanged; P5 ends with a barrier because the next
 // map's P1 overwrites the LDS row.
+// MULTIF (F > 1, the reference's sumAlongFeatures case): the walk runs over (map, feature) pairs.  The
+// image-spectrum row of feature f cannot stay in registers (F rows), so it is fetched at the start of
+// P3 -- from the XCD's L2: the workgroups walking the same row for other maps run beside this one --
+// and lands while the stage-3 butterfly is computed; the feature sum is kept in registers and only
+// the last feature runs the inverse phases.  What the walk still saves per map: the launch, the
+// twiddle fill, the store drain and the exposed kernel-row load of every (map, feature) step.
 #pragma once
 #include "fast_rows.hpp"
 
@@ -35,9 +41,10 @@
 
 namespace fc {
 
-template <class C>
+template <class C, bool MULTIF = false>
 struct RowMultiState {
-    c32 s[C::R3];        // image spectrum of this thread's stage-3 butterfly (whole walk)
+    c32 s[C::R3];        // image spectrum of this thread's stage-3 butterfly (F = 1: whole walk; MULTIF: one step)
+    c32 acc[MULTIF ? C::R3 : 1];   // feature sum of the current map (MULTIF)
     c32 x[C::RND1];      // kernel row of the current / next map
     c32 w1[C::RND1];     // stage-1 base twiddle w_L^j of this thread's butterflies (same for every map)
     int yoff[C::RND1];   // tiled intermediate: element offset of this thread's rows (same for every map)
@@ -50,18 +57,19 @@ inline bool fast_rows_multi_linear(const FastRowsArgs& g, int L, int m1) {
     return !tiled || (m1 & ((1 << g.y_tile_shift) - 1)) == 0;
 }
 
-template <class C, int NZ2, bool LINEAR, class Ctx>
+template <class C, int NZ2, bool LINEAR, bool MULTIF = false, class Ctx>
 FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, int kernel0, int nk, int rows) {
     constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
-    using State = RowMultiState<C>;
+    using State = RowMultiState<C, MULTIF>;
+    const int nF = MULTIF ? g.F : 1;
     c32* tw2 = lds + RPW * L;
     const int kw = g.kw;
     const int row0 = group * RPW;
     const bool tiled = g.y_row_of != nullptr;
     constexpr bool FOLD = !(FC_ROWS_NO_FOLD);
 
-    auto load_x = [&](int t, State& st, int kernel) {
-        const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride;
+    auto load_x = [&](int t, State& st, int kernel, int f) {
+        const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride + (MULTIF ? (size_t)f * g.a_feat_stride : 0);
         static_for<0, C::RND1>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const int u = t + NT * r;
@@ -74,7 +82,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
     // once per workgroup: stage-2 twiddles into LDS, first kernel row, image-spectrum row
     ctx.phase_nosync([&](int t, State& st) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
-        load_x(t, st, kernel0);
+        load_x(t, st, kernel0, 0);
         // loaded once: inside the walk a global load in P5 would have to be waited for together
         // with the stores issued just before it (one in-order memory counter)
         static_for<0, C::RND1>([&](auto r_) {
@@ -86,17 +94,19 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             st.w1[r] = live ? g.tw1[j] : mk(1.f, 0.f);
             st.yoff[r] = live ? (tiled ? (g.y_row_of[row] << g.y_tile_shift) : row * g.y_pitch) : 0;
         });
-        const int rr = t / C::NB3, q = t - rr * C::NB3;
-        if (rr < RPW && row0 + rr < rows) {
-            const c32* srow = g.S + (size_t)(row0 + rr) * g.s_pitch;
-            static_for<0, R3 / 2>([&](auto h_) {
-                constexpr int h = decltype(h_)::value;
-                c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
-                st.s[2 * h] = v.a;
-                st.s[2 * h + 1] = v.b;
-            });
-        } else {
-            static_for<0, R3>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
+        if constexpr (!MULTIF) {
+            const int rr = t / C::NB3, q = t - rr * C::NB3;
+            if (rr < RPW && row0 + rr < rows) {
+                const c32* srow = g.S + (size_t)(row0 + rr) * g.s_pitch;
+                static_for<0, R3 / 2>([&](auto h_) {
+                    constexpr int h = decltype(h_)::value;
+                    c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
+                    st.s[2 * h] = v.a;
+                    st.s[2 * h + 1] = v.b;
+                });
+            } else {
+                static_for<0, R3>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
+            }
         }
     });
 
@@ -110,7 +120,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         // stage 1 is the only one that ever touches them, so it writes the next map's stage-1
         // outputs into them right away, with the twiddle chain it has at hand -- one phase and one
         // barrier fewer per map
-        if (!FOLD || m == 0) ctx.phase([&](int t, State& st) {
+        for (int f = 0; f < nF; f++) {
+        if (!FOLD || m == 0 || f > 0) ctx.phase([&](int t, State& st) {
             static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int u = t + NT * r;
@@ -128,8 +139,9 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             });
         });
 
-        // the next kernel's row flies during P2..P5
-        if (m + 1 < nk) ctx.phase_nosync([&](int t, State& st) { load_x(t, st, kernel + 1); });
+        // the next kernel row (next feature of this map, or the next map's first) flies during P2..P5
+        if (f + 1 < nF) ctx.phase_nosync([&](int t, State& st) { load_x(t, st, kernel, f + 1); });
+        else if (m + 1 < nk) ctx.phase_nosync([&](int t, State& st) { load_x(t, st, kernel + 1, 0); });
 
         FC_ROWS_STAMP(1);
         // P2: forward stage 2
@@ -159,9 +171,23 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
 
         FC_ROWS_STAMP(2);
         // P3: forward stage 3, product with the image spectrum (registers), inverse stage 3
+        const bool last_f = (f == nF - 1);
         ctx.phase([&](int t, State& st) {
             const int rr = t / C::NB3, q = t - rr * C::NB3;
             if (rr < RPW) {
+                if constexpr (MULTIF) {   // this feature's image-spectrum row: in flight during the butterfly
+                    if (row0 + rr < rows) {
+                        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(row0 + rr) * g.s_pitch;
+                        static_for<0, R3 / 2>([&](auto h_) {
+                            constexpr int h = decltype(h_)::value;
+                            c32x2 w = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
+                            st.s[2 * h] = w.a;
+                            st.s[2 * h + 1] = w.b;
+                        });
+                    } else {
+                        static_for<0, R3>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
+                    }
+                }
                 c32* p = lds + rr * L + q * R3;
                 c32 v[R3];
                 static_for<0, R3 / 2>([&](auto h_) {
@@ -170,21 +196,58 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     v[2 * h] = w.a;
                     v[2 * h + 1] = w.b;
                 });
+                if constexpr (MULTIF) {
+                    // The R3 LDS cells this thread has just read are its own until the next barrier: the
+                    // feature sum is parked there while the butterfly runs beside the in-flight image row
+                    // (sum + image row + butterfly do not fit the register file together: 58-100 spilled
+                    // registers otherwise) and comes back, pair by pair, into the accumulation.
+                    if (f > 0) {
+                        static_for<0, R3 / 2>([&](auto h_) {
+                            constexpr int h = decltype(h_)::value;
+                            c32x2 w;
+                            w.a = st.acc[2 * h];
+                            w.b = st.acc[2 * h + 1];
+                            *reinterpret_cast<c32x2*>(p + 2 * h) = w;
+                        });
+                    }
+                    FC_SCHED_FENCE();
+                }
                 Dft<R3, -1>::run(v);
-                static_for<0, R3>([&](auto a_) {
-                    constexpr int a = decltype(a_)::value;
-                    v[a] = cmul(v[a], st.s[a]);
-                });
-                Dft<R3, +1>::run(v);
-                static_for<0, R3 / 2>([&](auto h_) {
-                    constexpr int h = decltype(h_)::value;
-                    c32x2 w;
-                    w.a = v[2 * h];
-                    w.b = v[2 * h + 1];
-                    *reinterpret_cast<c32x2*>(p + 2 * h) = w;
-                });
+                if constexpr (!MULTIF) {
+                    static_for<0, R3>([&](auto a_) {
+                        constexpr int a = decltype(a_)::value;
+                        v[a] = cmul(v[a], st.s[a]);
+                    });
+                } else {
+                    FC_SCHED_FENCE();
+                    static_for<0, R3 / 2>([&](auto h_) {
+                        constexpr int h = decltype(h_)::value;
+                        c32 pa = cmul(v[2 * h], st.s[2 * h]);
+                        c32 pb = cmul(v[2 * h + 1], st.s[2 * h + 1]);
+                        if (f > 0) {
+                            const c32x2 w = *reinterpret_cast<const c32x2*>(p + 2 * h);
+                            pa = pa + w.a;
+                            pb = pb + w.b;
+                        }
+                        st.acc[2 * h] = pa;
+                        st.acc[2 * h + 1] = pb;
+                        v[2 * h] = pa;
+                        v[2 * h + 1] = pb;
+                    });
+                }
+                if (!MULTIF || last_f) {
+                    Dft<R3, +1>::run(v);
+                    static_for<0, R3 / 2>([&](auto h_) {
+                        constexpr int h = decltype(h_)::value;
+                        c32x2 w;
+                        w.a = v[2 * h];
+                        w.b = v[2 * h + 1];
+                        *reinterpret_cast<c32x2*>(p + 2 * h) = w;
+                    });
+                }
             }
         });
+        }   // features
 
         FC_ROWS_STAMP(3);
         // P4: inverse stage 2

@@ -21,7 +21,7 @@ struct PlanTuning {
     // 0 generic kernels only; 1 specialised kernels with a row-major intermediate; 2 (default)
     // specialised kernels with the tiled, pair-adjacent intermediate
     int path_mode = 2;
-    // maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp, F = 1): -1 = chosen per
+    // maps per workgroup of the multi-map row kernel (fast_rows_multi.hpp): -1 = chosen per
     // launch (rows_group_for), 0 / 1 = plain one-map kernel, > 1 = fixed
     int rows_group = -1;
     // largest transform length a plan may use (0 = whatever fits the LDS); larger problems are left
@@ -61,13 +61,22 @@ struct Geometry {
     int tile_rows() const { return y_tiled() ? M + 2 : rows; }
     int rows_wg_order = 0;     // workgroup order of the one-map row kernel (kernels_rows.hip: k_fast_rows); 2 for F > 1
     int rows_group = -1;       // PlanTuning::rows_group
-    bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && F == 1 && fast_rows.ok; }
+    bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && fast_rows.ok; }
     // As many maps per workgroup as leaves >= 4 workgroups per resident slot (4 per CU), at most 16:
     // the walk amortises the image-spectrum row, the launch and the store drain, but a grid
     // that no longer fills the chip loses more than that.
     int rows_group_for(int nmaps, int num_cus) const {
         if (!rows_multi_ok()) return 1;
         if (rows_group > 1) return std::min(rows_group, nmaps);
+        const int g1 = rows_group_auto(nmaps, num_cus);
+        if (F == 1) return g1;
+        // F > 1: the F image-spectrum rows of a workgroup are re-read for every map from the XCD's L2, and they
+        // stay there only while few row groups are in flight per XCD, i.e. while many workgroups share a row
+        // group: short walks (measured optimum 4-6 maps at F <= 8, 2 at F = 32; tools/f_group.py,
+        // profiles/r02x_f_walk_length.txt: 16-map walks fetch 205 MB per map at F = 8, 4-map walks 62)
+        return std::min(g1, std::max(2, std::min(6, 32 / F)));
+    }
+    int rows_group_auto(int nmaps, int num_cus) const {
         const long groups = (rows + fast_rows.RPW - 1) / fast_rows.RPW;
         const long g = groups * nmaps / ((long)num_cus * 16);
         if (g < 1) {

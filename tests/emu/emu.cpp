@@ -55,15 +55,21 @@ struct EmuFastRows {
                      // the prefetch slot and the LDS reuse are exercised, the indexing is not
     template <class Cfg, int NZ2>
     void go() {
-        if (group > 1 && a.F == 1) {
+        if (group > 1) {
             FastRowsArgs b = a;
             b.a_kernel_stride = 0;
             b.y_kernel_stride = 0;
             for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
                 for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-                HostPhaseCtx<RowMultiState<Cfg>> ctx(Cfg::NT);
-                if (fast_rows_multi_linear(b, Cfg::L, Cfg::m1)) fast_rows_multi_body<Cfg, NZ2, true>(ctx, lds, b, grp, 0, group, rows);
-                else fast_rows_multi_body<Cfg, NZ2, false>(ctx, lds, b, grp, 0, group, rows);
+                if (a.F > 1) {   // the walk over (map, feature) pairs
+                    HostPhaseCtx<RowMultiState<Cfg, true>> ctx(Cfg::NT);
+                    if (fast_rows_multi_linear(b, Cfg::L, Cfg::m1)) fast_rows_multi_body<Cfg, NZ2, true, true>(ctx, lds, b, grp, 0, group, rows);
+                    else fast_rows_multi_body<Cfg, NZ2, false, true>(ctx, lds, b, grp, 0, group, rows);
+                } else {
+                    HostPhaseCtx<RowMultiState<Cfg>> ctx(Cfg::NT);
+                    if (fast_rows_multi_linear(b, Cfg::L, Cfg::m1)) fast_rows_multi_body<Cfg, NZ2, true>(ctx, lds, b, grp, 0, group, rows);
+                    else fast_rows_multi_body<Cfg, NZ2, false>(ctx, lds, b, grp, 0, group, rows);
+                }
             }
             return;
         }

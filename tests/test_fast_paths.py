@@ -129,7 +129,9 @@ def test_emulated_fast_kernels_other_configs(emu, oracle, tuned, shape, mode):
         assert util.rel_err(g, r) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [ROW_SHAPES[0], (256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 1), (2048, 300, 1, 63, 20, 1)])
+@pytest.mark.parametrize("shape", [ROW_SHAPES[0], (256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 1), (2048, 300, 1, 63, 20, 1),
+                                   # F > 1: the walk over (map, feature) pairs (feature sum in registers)
+                                   (300, 4096, 2, 20, 63, 1), (250, 280, 3, 9, 9, 2), (540, 500, 5, 37, 40, 1), (200, 2048, 2, 9, 63, 1)])
 def test_emulated_multi_map_row_kernel(emu, oracle, tuned, shape):
     """fast_rows_multi.hpp (several maps per workgroup): the walk, its prefetch slot and the LDS reuse
     through the emulator (which repeats one kernel; distinct kernels per walk are a GPU test)"""
