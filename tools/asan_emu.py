@@ -10,7 +10,7 @@ def conv(data,mkh,mkw,ks):
     rc=emu.emu_conv_fft(ctypes.c_void_p(d.ctypes.data),H,W,F,mkh,mkw,n,kp,kh,kw,op,None,None)
     assert rc==0, rc
     return outs
-shapes=[(64,8,5,10,4,3),(256,256,1,31,31,1),(1024,1024,1,63,63,1),(300,260,1,63,63,2),(40,4096,1,7,127,1),(4096,24,1,127,9,1),(2048,300,1,63,20,1),(512,512,2,31,31,1),(57,57,1,9,9,1),(33,47,3,7,5,2)]
+shapes=[(64,8,5,10,4,3),(256,256,1,31,31,1),(1024,1024,1,63,63,1),(300,260,1,63,63,2),(40,4096,1,7,127,1),(4096,24,1,127,9,1),(2048,300,1,63,20,1),(512,512,2,31,31,1),(300,4096,2,20,63,1),(200,2048,3,9,63,2),(57,57,1,9,9,1),(33,47,3,7,5,2)]
 for mode,grp in [(2,-1),(2,3),(1,-1),(0,-1)]:
     emu.emu_set_tuning(mode,grp)
     for sh in shapes:
