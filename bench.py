@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="--filters (or the config's count) is per GPU: weak scaling")
     ap.add_argument("--batch-maps", type=int, default=0)
     ap.add_argument("--kernel-chunk-mb", type=int, default=0, help="budget of the kernels' column-spectrum chunk (0 = the library's default; A/B)")
+    ap.add_argument("--tune-placement", type=int, default=-1,
+                    help="candidate allocations of the intermediate the plan times against the map buffer (plan option "
+                         "tune_placement; -1 = 3 where a launch covers >= 5e8 padded pixels, else off; 0 = off)")
     ap.add_argument("--rows-group", type=int, default=0, help="maps per workgroup of the spectral-row kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
@@ -253,6 +256,10 @@ def main():
         plan.set_option("rows_group", args.rows_group)
     if args.kernel_chunk_mb:
         plan.set_option("kernel_chunk_mb", args.kernel_chunk_mb)
+    # placement tuning (untimed set-up, like a plan's measuring): only where launches are long enough to tell 4 % apart
+    tune_k = args.tune_placement if args.tune_placement >= 0 else (3 if min(args.batch_maps or 64, max(nf, 1)) * P >= 5e8 else 0)
+    if tune_k > 1:
+        plan.set_option("tune_placement", tune_k)
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
     # the next image's H2D copy (streamed mode)
     overlap = streamed or ((use_dist or args.overlap) and not args.no_overlap)
@@ -460,6 +467,7 @@ def main():
                        "filters_total": nf_total,
                        "filters_per_gpu": nf if streamed else -(-nf_total // world),
                        "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps,
+                       "tune_placement": {"candidates": plan.get_option("tuned_candidates"), "kept": plan.get_option("tuned_best")} if tune_k > 1 else None,
                        "images_per_step": args.images if streamed else 1,
                        "parallelism": ("images x%d, streamed H2D" % world) if streamed else
                                       ("filters x%d + 1 bcast per step" % world if world > 1 else "single GPU")},

@@ -86,7 +86,7 @@ EXPORTED_SYMBOLS = (
     "fftconv_plan_use_spectrum_buffer", "fftconv_plan_export_spectrum", "fftconv_plan_import_spectrum",
     "fftconv_plan_convolve", "fftconv_plan_convolve_packed", "fftconv_plan_prepare_kernels_packed",
     "fftconv_plan_synchronize", "fftconv_plan_set_stream",
-    "fftconv_plan_set_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
+    "fftconv_plan_set_option", "fftconv_plan_get_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
     "fftconv_multi_create", "fftconv_multi_destroy", "fftconv_multi_set_image", "fftconv_multi_import_spectrum",
     "fftconv_multi_convolve",
     "fftconv_multi_shard", "fftconv_multi_size", "fftconv_multi_plan", "fftconv_convolution_fft_multi",
@@ -152,6 +152,7 @@ def load_library():
     lib.fftconv_plan_synchronize.argtypes = [vp]
     lib.fftconv_plan_set_stream.argtypes = [vp, vp]
     lib.fftconv_plan_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
+    lib.fftconv_plan_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]
     lib.fftconv_plan_get_profile.argtypes = [vp, ctypes.POINTER(Profile), ci]
     lib.fftconv_fft_data.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
     lib.fftconv_conv_fft_data.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp]
@@ -367,6 +368,11 @@ class Plan:
     def set_option(self, name, value):
         _check(self._lib.fftconv_plan_set_option(self._h, name.encode(), int(value)))
         _check(self._lib.fftconv_plan_get_info(self._h, ctypes.byref(self.info)))
+
+    def get_option(self, name):
+        v = ctypes.c_long(0)
+        _check(self._lib.fftconv_plan_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def profile(self, reset=True):
         pr = Profile()

@@ -90,11 +90,13 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
+    bool fresh = false;   // (re)allocated since the flag was last cleared
     int ensure(size_t n) {
         if (n <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        fresh = true;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
         if (e != hipSuccess) {
             p = nullptr;
@@ -298,6 +300,8 @@ struct fftconv_plan {
     int num_cus = 256;
     long opt_batch_maps = 0;
     long opt_kernel_chunk_mb = 0;
+    int tuned_candidates = 0, tuned_best = 0;   // of the last placement tuning (fftconv_plan_get_option)
+    long opt_tune_placement = 0;   // > 1: that many candidate allocations of the intermediate are tried (tune_intermediate_placement)
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
     long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
@@ -543,6 +547,84 @@ int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh,
     return p->prof_end();
 }
 
+// Opt-in placement tuning of the intermediate (option tune_placement = k > 1).  On this memory system the
+// output kernel runs in one of two states, 4 % apart, and WHICH physical allocations hold the intermediate
+// and the maps decides it (profiles/r02x_placement_class_map.txt); nothing in user space can
+// ask for the fast pairing, but it can be found: right after the intermediate was (re)allocated, up to k
+// candidate allocations of it are timed with the real output kernel writing into the caller's map buffer
+// (interleaved, after ~50 ms of load so that the clocks have settled), the fastest is kept, the others are
+// freed.  The probes write into `out`, which the convolve that follows overwrites; they read the candidates as
+// allocated (the driver hands out zeroed memory).  Blocking (~70 ms), once per allocation: what FFTW calls
+// measuring at plan time.
+int tune_intermediate_placement(fftconv_plan* p, int n, int nbY, float* out, size_t out_stride_per_map) {
+    // (out_stride_per_map > 0: the call's batches write to out + first_map * stride, and every batch's
+    // destination is probed -- an 18-GB map buffer spans several placement regions; 0: one staging buffer)
+    const Geometry& g = p->g;
+    const int k = (int)p->opt_tune_placement;
+    p->Y.fresh = false;
+    if (k < 2 || !g.fast_cols.ok || n < 1) return 0;
+    const int nbatch = out_stride_per_map ? std::min(16, (n + nbY - 1) / nbY) : 1;
+    std::vector<DevBuf<c32>> cand((size_t)k);
+    cand[0] = p->Y;
+    p->Y = DevBuf<c32>();
+    int nc = 1;
+    for (; nc < k; nc++) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&cand[nc].p), cand[0].cap * sizeof(c32));
+        if (e != hipSuccess) { (void)hipGetLastError(); cand[nc].p = nullptr; break; }   // as many as fit
+        cand[nc].cap = cand[0].cap;
+    }
+    auto launch = [&](const DevBuf<c32>& y) -> hipError_t {   // the output launches of the whole call
+        for (int b = 0; b < nbatch; b++) {
+            const int ny = std::min(nbY, n - b * nbY);
+            FastColsArgs fa = fast_cols_args(g, p->d, y.p, out + (size_t)b * nbY * out_stride_per_map, g.map_elems(), ny);
+            hipError_t e = launch_fast_cols(g.M, g.fast_cols.T, fa, p->num_cus, p->stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    int best = 0;
+    hipError_t err = hipSuccess;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<double> ms((size_t)nc, 0.0);
+    do {
+        if (nc < 2) break;
+        if ((err = hipEventCreate(&ev[0])) != hipSuccess || (err = hipEventCreate(&ev[1])) != hipSuccess) break;
+        // settle the clocks: ~50 ms of this kernel, measured with the first launch
+        if ((err = hipEventRecord(ev[0], p->stream)) != hipSuccess || (err = launch(cand[0])) != hipSuccess ||
+            (err = hipEventRecord(ev[1], p->stream)) != hipSuccess || (err = hipEventSynchronize(ev[1])) != hipSuccess) break;
+        float one = 0.f;
+        if ((err = hipEventElapsedTime(&one, ev[0], ev[1])) != hipSuccess) break;
+        const int warm = std::min(200, std::max(2, (int)(50.0f / std::max(one, 0.05f))));
+        for (int i = 0; i < warm && err == hipSuccess; i++) err = launch(cand[i % nc]);
+        if (err != hipSuccess) break;
+        for (int rep = 0; rep < 3 && err == hipSuccess; rep++)
+            for (int c = 0; c < nc && err == hipSuccess; c++) {
+                float t = 0.f;
+                if ((err = hipEventRecord(ev[0], p->stream)) != hipSuccess || (err = launch(cand[c])) != hipSuccess ||
+                    (err = hipEventRecord(ev[1], p->stream)) != hipSuccess || (err = hipEventSynchronize(ev[1])) != hipSuccess ||
+                    (err = hipEventElapsedTime(&t, ev[0], ev[1])) != hipSuccess) break;
+                ms[c] += t;
+            }
+        if (err != hipSuccess) break;
+        for (int c = 1; c < nc; c++)
+            if (ms[c] < ms[best]) best = c;
+    } while (false);
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipStreamSynchronize(p->stream);
+    for (int c = 0; c < nc; c++) {
+        if (c == best) continue;
+        if (cand[c].p) (void)hipFree(cand[c].p);
+        cand[c].p = nullptr;
+    }
+    p->Y = cand[best];
+    p->Y.fresh = false;
+    p->tuned_candidates = nc;
+    p->tuned_best = best;
+    if (err != hipSuccess) return fail(FFTCONV_ERR_HIP, "placement tuning failed: %s", hipGetErrorString(err));
+    return 0;
+}
+
 // Core of the per-kernel loop (src/cudaConvolutionFFT.cu:204-291) for n kernels of one size,
 // packed on the device at dk ([n][F][kw][kh]).
 int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, const Sink& sink) {
@@ -568,6 +650,14 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
         if (int rc = stage.ensure(oe * nbY * (streamed ? 2 : 1))) return rc;
     if (streamed)
         if (int rc = ring_ensure(p)) return rc;
+    if (p->Y.fresh) {   // before anything is written into it: the tuner may keep another allocation
+        if (p->opt_tune_placement > 1) {
+            const bool direct = !cropped && !staged;   // the output kernel writes straight into the caller's packed buffer
+            float* first_obase = cropped ? p->O.p : (staged ? stage.p : sink.packed);
+            if (int rc = tune_intermediate_placement(p, direct ? n : std::min(nbY, n), nbY, first_obase, direct ? oe : 0)) return rc;
+        }
+        p->Y.fresh = false;
+    }
     int batch = 0;
     struct { bool valid = false; int first = 0, count = 0, buf = 0; } prev;
 
@@ -1079,6 +1169,7 @@ int fftconv_plan_synchronize(fftconv_plan* plan) {
 
 int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (!strcmp(name, "tune_placement")) { plan->opt_tune_placement = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
@@ -1114,6 +1205,21 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
          : name[5] == 'c' ? plan->opt_host_chunk_kb : plan->opt_host_slots) = value;
         return 0;
     }
+    return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
+    if (!plan || !name || !value) return fail(FFTCONV_ERR_INVALID_ARG, "null argument");
+    if (!strcmp(name, "batch_maps")) { *value = plan->opt_batch_maps; return 0; }
+    if (!strcmp(name, "kernel_chunk_mb")) { *value = plan->opt_kernel_chunk_mb; return 0; }
+    if (!strcmp(name, "tune_placement")) { *value = plan->opt_tune_placement; return 0; }
+    if (!strcmp(name, "tuned_candidates")) { *value = plan->tuned_candidates; return 0; }
+    if (!strcmp(name, "tuned_best")) { *value = plan->tuned_best; return 0; }
+    if (!strcmp(name, "rows_group")) { *value = plan->g.rows_group; return 0; }
+    if (!strcmp(name, "host_stream")) { *value = plan->opt_host_stream; return 0; }
+    if (!strcmp(name, "output_region")) { *value = plan->opt_region; return 0; }
+    if (!strcmp(name, "flip_kernels")) { *value = plan->opt_flip_kernels; return 0; }
+    if (!strcmp(name, "profile")) { *value = plan->profile ? 1 : 0; return 0; }
     return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

@@ -239,6 +239,11 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
 /* Options: "batch_maps" (kernels per spectral/output launch, 0 = auto),
  *          "kernel_chunk_mb" (0 = auto: the kernels' column spectra are produced one launch's worth at a
  *             time, right before the row kernel reads them; > 0: as many launches' worth as fit that many MiB),
+ *          "tune_placement" (k > 1: the next time the intermediate buffer is (re)allocated, k candidate
+ *             allocations of it are timed with the output kernel writing into the caller's map buffer and
+ *             the fastest is kept -- on MI355X the output kernel runs 4 % faster or slower depending on which
+ *             physical allocations hold its two buffers; blocking, ~70 ms, once per
+ *             allocation; 0 (default): off),
  *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
  *          "profile" (1: time every kernel launch with HIP events on the plan's stream),
  *          "profile_kinds" (bit mask over the indices of fftconv_profile: only those kinds are timed
@@ -262,6 +267,9 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             demoCudaConvolutionFFT.m:63-69 done here instead of in MATLAB; the reference keeps a
  *             conjugate-product variant commented out, src/cudaConvFFTData.cuh:42-45,63). */
 int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
+/* Current value of an option, plus two read-only ones about the last placement tuning:
+ * "tuned_candidates" (allocations tried) and "tuned_best" (index of the one kept). */
+int fftconv_plan_get_option(fftconv_plan *plan, const char *name, long *value);
 
 typedef struct fftconv_profile {
     /* accumulated since the last reset; index 0 kernel_cols (h forward of the kernels),

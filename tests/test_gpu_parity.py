@@ -217,6 +217,43 @@ def test_prepare_kernels_split(fc, oracle):
             assert util.rel_err(out[j].cpu().numpy().T, 2.0 * ref[j]) < TIGHT
 
 
+def test_placement_tuning_keeps_results(fc, oracle):
+    """option tune_placement: candidate allocations of the intermediate are timed against the map buffer
+    before the first convolve writes anything; results are those of an untuned plan, the tuning happens once
+    per allocation, and the getter reports it (device-resident and host-output destinations)"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H, W, F, kh, kw, n = 1024, 1024, 1, 63, 63, 5
+    img, ks = util.synth(77, H, W, F, kh, kw, n)
+    ref = oracle.conv_fft(img, kh, kw, ks)
+    k_d = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in ks]))).to(dev)
+    with fc.Plan(H, W, F, kh, kw) as p:
+        assert p.get_option("tune_placement") == 0 and p.get_option("tuned_candidates") == 0
+        p.set_option("tune_placement", 3)
+        p.set_option("batch_maps", 2)            # three launches per call: every batch's destination is probed
+        p.set_image(img)
+        out = torch.full((n, p.info.fft_w, p.info.fft_h), float("nan"), dtype=torch.float32, device=dev)
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+        assert p.get_option("tuned_candidates") == 3 and 0 <= p.get_option("tuned_best") < 3
+        for j in range(n):
+            assert util.rel_err(out[j].cpu().numpy().T, ref[j]) < TIGHT
+        out.fill_(float("nan"))
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())   # same allocation: not tuned again
+        p.synchronize()
+        for j in range(n):
+            assert util.rel_err(out[j].cpu().numpy().T, ref[j]) < TIGHT
+        with pytest.raises(fc.FFTConvError):
+            p.get_option("no_such_option")
+    with fc.Plan(H, W, F, kh, kw) as p:          # host-output destination: the staging buffer is what is probed
+        p.set_option("tune_placement", 2)
+        p.set_image(img)
+        got = p.convolve(ks)
+        assert p.get_option("tuned_candidates") == 2
+        for g, r in zip(got, ref):
+            assert util.rel_err(g, r) < TIGHT
+
+
 def test_external_spectrum_buffer_roundtrip(fc, oracle):
     """the multi-GPU hand-off: spectrum produced into caller memory by one plan, consumed by another"""
     torch = pytest.importorskip("torch")
