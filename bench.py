@@ -18,8 +18,13 @@ every image against all kernels, H2D of the next image behind the compute of the
 
 The steps themselves live in cuda-fft-convolution_amd/multi_gpu.py (shared with the tests).
 
+Untimed set-up and warm-up: for cfg3 / cfg4 the plan times candidate allocations of its intermediate
+against the map buffer and keeps the fastest (plan option tune_placement); the W warm-up
+steps are followed by more untimed steps where they are shorter than the ~40 ms the GPU's clocks
+need to settle after an idle gap (config.clock_warm_steps).  The timed region is exactly K steps.
+
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
-kernel, algorithmic bytes / live HIP-event time), `cpu_baseline` (the CPU oracle timed on this
+kernel, algorithmic bytes / its HIP-event time over the launches of the timed region itself), `cpu_baseline` (the CPU oracle timed on this
 host on a bounded sample, rank 0 at N = 1 only) and `check_max_rel_err` (every map's checksum on
 the device + the oracle's maps where they were computed); a failed check exits non-zero.
 """
