@@ -303,6 +303,7 @@ struct fftconv_plan {
     int tuned_candidates = 0, tuned_best = 0;   // of the last placement tuning (fftconv_plan_get_option)
     long opt_tune_placement = 0;   // > 1: that many candidate allocations of the intermediate are tried (tune_intermediate_placement)
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
+    long opt_host_min_kb = 1024;   // maps smaller than this leave by blocking copies whatever host_stream says
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
     long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
     long opt_host_slots = 0;       // ring chunks (0 = auto)
@@ -638,7 +639,14 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
     const bool staged = (sink.packed == nullptr);
     // host output: two staging buffers, the copy-out of batch b overlaps the compute of batch b + 1
-    const bool streamed = staged && sink.location == FFTCONV_HOST && p->opt_host_stream != 0;
+    // ... for maps of at least host_min_kb (1 MiB).  Smaller ones leave by blocking copies on the plan's stream:
+    // the copy threads buy them nothing (a one-shot call would start and join them for a few hundred KB), and
+    // small destination buffers are heap neighbours that share pages, which the runtime pins in place from
+    // several threads at once.  A one-shot call on 92-KB maps died (SIGABRT / SIGSEGV, no message) about once
+    // in 50-100 runs of tests/test_gpu_parity.py::test_blockwise_one_shot_matches_oracle on some boxes of the
+    // pool and never on others; the cause was not isolated, these threads are what that call had to itself.
+    const bool streamed = staged && sink.location == FFTCONV_HOST && p->opt_host_stream != 0 &&
+                          p->out_elems() * sizeof(float) >= ((size_t)p->opt_host_min_kb << 10);
     // a region other than the whole window: the output kernel writes the window into O, a crop
     // kernel compacts the region into the destination (the caller's packed buffer or the staging OC)
     const bool cropped = p->opt_region != 0;
@@ -1195,6 +1203,11 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         return 0;
     }
     if (!strcmp(name, "flip_kernels")) { plan->opt_flip_kernels = value != 0; plan->prepared.dk = nullptr; return 0; }
+    if (!strcmp(name, "host_min_kb")) {
+        if (value < 0 || value > (1 << 30)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);
+        plan->opt_host_min_kb = value;
+        return 0;
+    }
     if (!strcmp(name, "host_stream") || !strcmp(name, "host_threads") || !strcmp(name, "host_chunk_kb") || !strcmp(name, "host_slots")) {
         if (value < 0 || value > (1 << 20)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);
         if (int rc = use_device(plan)) return rc;
@@ -1217,6 +1230,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "tuned_best")) { *value = plan->tuned_best; return 0; }
     if (!strcmp(name, "rows_group")) { *value = plan->g.rows_group; return 0; }
     if (!strcmp(name, "host_stream")) { *value = plan->opt_host_stream; return 0; }
+    if (!strcmp(name, "host_min_kb")) { *value = plan->opt_host_min_kb; return 0; }
     if (!strcmp(name, "output_region")) { *value = plan->opt_region; return 0; }
     if (!strcmp(name, "flip_kernels")) { *value = plan->opt_flip_kernels; return 0; }
     if (!strcmp(name, "profile")) { *value = plan->profile ? 1 : 0; return 0; }

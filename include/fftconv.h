@@ -254,6 +254,8 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             batch; 1 (default) = host threads of the plan copy batch b straight into the caller's
  *             buffers while batch b+1 is computed; 2 = through a ring of pinned chunks),
  *          "host_threads", "host_chunk_kb", "host_slots" (shape of that machinery, 0 = auto),
+ *          "host_min_kb" (maps smaller than this many KiB leave by blocking copies whatever "host_stream"
+ *             says; default 1024: the copy threads buy small maps nothing),
  *          "output_region" (which part of the padded window a result map holds, for the plan's
  *             MAX_KERNEL sizes K: 0 (default) the whole FFT_H x FFT_W window as the reference
  *             returns it; 1 "full" = the linear convolution, (DATA + K - 1), what the demo crops by
