@@ -132,7 +132,7 @@ struct HostRing {
     std::vector<hipEvent_t> landed;    // per slot: its D2H copy has finished
     hipEvent_t compute_done[2] = {nullptr, nullptr};  // per device staging buffer
     hipEvent_t copy_done[2] = {nullptr, nullptr};
-    struct Task { int slot; char* dst; size_t bytes; const char* src; int buf; };  // slot < 0: direct copy from src
+    struct Task { int slot; char* dst; size_t bytes; const char* src; int buf; bool pinned; };  // slot < 0: direct copy from src (pinned: the caller pinned dst itself)
     std::deque<Task> q;
     std::mutex m;
     std::condition_variable cv_task, cv_slot;
@@ -162,10 +162,38 @@ struct HostRing {
         (void)hipSetDevice(gpu_id);
         hipStream_t own = nullptr;
         if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = copy_stream;
-        work_loop(own);
+        char* bounce = nullptr;   // two pages of pinned memory for the unaligned ends of a destination
+        if (hipHostMalloc(reinterpret_cast<void**>(&bounce), 8192, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            bounce = nullptr;
+        }
+        work_loop(own, bounce);
+        if (bounce) (void)hipHostFree(bounce);
         if (own != copy_stream) (void)hipStreamDestroy(own);
     }
-    void work_loop(hipStream_t own) {
+    // Device -> pageable caller memory.  The runtime pins the destination pages in place; destinations of
+    // different maps may be heap neighbours that share their first / last page, and those pages would be pinned by
+    // two threads at once.  So only the whole pages INSIDE the destination take the direct road; the unaligned
+    // head and tail (< 4 KB each) land in this thread's pinned bounce buffer and are copied by the CPU.
+    static hipError_t copy_out(char* dst, const char* src, size_t n, hipStream_t own, char* bounce) {
+        size_t head = (size_t)((4096 - (reinterpret_cast<uintptr_t>(dst) & 4095)) & 4095);
+        if (!bounce) head = 0;
+        if (head > n) head = n;
+        const size_t tail = bounce ? ((n - head) & 4095) : 0;
+        const size_t mid = n - head - tail;
+        hipError_t e = hipSuccess;
+        if (mid) {
+            prefault(dst + head, mid);
+            e = hipMemcpyAsync(dst + head, src + head, mid, hipMemcpyDeviceToHost, own);
+        }
+        if (e == hipSuccess && head) e = hipMemcpyAsync(bounce, src, head, hipMemcpyDeviceToHost, own);
+        if (e == hipSuccess && tail) e = hipMemcpyAsync(bounce + 4096, src + head + mid, tail, hipMemcpyDeviceToHost, own);
+        if (e == hipSuccess) e = hipStreamSynchronize(own);
+        if (e == hipSuccess && head) memcpy(dst, bounce, head);
+        if (e == hipSuccess && tail) memcpy(dst + head + mid, bounce + 4096, tail);
+        return e;
+    }
+    void work_loop(hipStream_t own, char* bounce) {
         for (;;) {
             Task t;
             {
@@ -177,10 +205,8 @@ struct HostRing {
             }
             hipError_t e;
             if (t.slot < 0) {
-                prefault(t.dst, t.bytes);
                 e = hipStreamWaitEvent(own, compute_done[t.buf], 0);
-                if (e == hipSuccess) e = hipMemcpyAsync(t.dst, t.src, t.bytes, hipMemcpyDeviceToHost, own);
-                if (e == hipSuccess) e = hipStreamSynchronize(own);
+                if (e == hipSuccess) e = copy_out(t.dst, t.src, t.bytes, own, t.pinned ? nullptr : bounce);
             } else {
                 e = hipEventSynchronize(landed[t.slot]);
                 if (e == hipSuccess) memcpy(t.dst, base + (size_t)t.slot * chunk_bytes, t.bytes);
@@ -207,11 +233,11 @@ struct HostRing {
         cv_slot.notify_all();
     }
     void submit(int slot, char* dst, size_t bytes) {
-        { std::lock_guard<std::mutex> lk(m); q.push_back(Task{slot, dst, bytes, nullptr, 0}); open_tasks++; }
+        { std::lock_guard<std::mutex> lk(m); q.push_back(Task{slot, dst, bytes, nullptr, 0, false}); open_tasks++; }
         cv_task.notify_one();
     }
-    void submit_direct(const char* src, char* dst, size_t bytes, int buf) {
-        { std::lock_guard<std::mutex> lk(m); q.push_back(Task{-1, dst, bytes, src, buf}); open_tasks++; open_direct[buf]++; }
+    void submit_direct(const char* src, char* dst, size_t bytes, int buf, bool pinned) {
+        { std::lock_guard<std::mutex> lk(m); q.push_back(Task{-1, dst, bytes, src, buf, pinned}); open_tasks++; open_direct[buf]++; }
         cv_task.notify_one();
     }
     // the direct copies out of staging buffer `buf` have finished: it may be overwritten
@@ -499,7 +525,7 @@ int ring_drain(fftconv_plan* p, const Sink& sink, int first, int count, int buf,
     if (r->nslots == 0) {   // direct: whole maps, one per host thread at a time
         for (int j = 0; j < count; j++)
             r->submit_direct(reinterpret_cast<const char*>(staging + (size_t)j * p->out_elems()),
-                             reinterpret_cast<char*>(sink.ptrs[first + j]), map_bytes, buf);
+                             reinterpret_cast<char*>(sink.ptrs[first + j]), map_bytes, buf, caller_pinned(sink.ptrs[first + j]));
         return 0;
     }
     HIP_TRY(hipStreamWaitEvent(r->copy_stream, r->compute_done[buf], 0));
