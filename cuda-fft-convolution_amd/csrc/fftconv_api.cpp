@@ -24,6 +24,13 @@
 
 using namespace fc;
 
+#ifndef FC_HOST_MIN_KB
+#define FC_HOST_MIN_KB 1024    // (diagnostic builds set 0 to reproduce the small-map incident)
+#endif
+#ifndef FC_HOST_BOUNCE
+#define FC_HOST_BOUNCE 1       // 0: diagnostic builds, whole destinations by direct DMA as before
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -158,18 +165,31 @@ struct HostRing {
         (void)dst; (void)bytes;
 #endif
     }
-    void work() {
-        (void)hipSetDevice(gpu_id);
-        hipStream_t own = nullptr;
-        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = copy_stream;
-        char* bounce = nullptr;   // two pages of pinned memory for the unaligned ends of a destination
-        if (hipHostMalloc(reinterpret_cast<void**>(&bounce), 8192, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            bounce = nullptr;
+    // Streams and bounce buffers of the copy threads are created HERE, by the thread that owns the plan, before the
+    // threads start, and destroyed by it after they were joined: several fresh threads calling
+    // hipStreamCreateWithFlags at the same time corrupted the runtime's heap about once in 50 starts (glibc abort
+    // in free() inside libhsa-runtime64 under hipStreamCreateWithFlags -- native backtrace in
+    // profiles/r02y_host_thread_stream_create_abort.txt; that was the small-map incident of DESIGN.md 6).
+    std::vector<hipStream_t> own_streams;
+    char* bounce_base = nullptr;       // two pinned pages per copy thread (unaligned ends of a destination)
+    hipError_t prepare_workers(int nthreads) {
+        if (FC_HOST_BOUNCE) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&bounce_base), (size_t)8192 * nthreads, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                bounce_base = nullptr;
+            }
         }
-        work_loop(own, bounce);
-        if (bounce) (void)hipHostFree(bounce);
-        if (own != copy_stream) (void)hipStreamDestroy(own);
+        for (int i = 0; i < nthreads; i++) {
+            hipStream_t st = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+            own_streams.push_back(st);
+        }
+        return hipSuccess;
+    }
+    void work(int i) {
+        (void)hipSetDevice(gpu_id);
+        work_loop(own_streams[i], bounce_base ? bounce_base + (size_t)8192 * i : nullptr);
     }
     // Device -> pageable caller memory.  The runtime pins the destination pages in place; destinations of
     // different maps may be heap neighbours that share their first / last page, and those pages would be pinned by
@@ -261,6 +281,10 @@ struct HostRing {
             for (std::thread& t : workers) t.join();
             workers.clear();
         }
+        for (hipStream_t st : own_streams) (void)hipStreamDestroy(st);
+        own_streams.clear();
+        if (bounce_base) (void)hipHostFree(bounce_base);
+        bounce_base = nullptr;
         for (hipEvent_t e : landed) (void)hipEventDestroy(e);
         landed.clear();
         for (int i = 0; i < 2; i++) {
@@ -329,7 +353,7 @@ struct fftconv_plan {
     int tuned_candidates = 0, tuned_best = 0;   // of the last placement tuning (fftconv_plan_get_option)
     long opt_tune_placement = 0;   // > 1: that many candidate allocations of the intermediate are tried (tune_intermediate_placement)
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
-    long opt_host_min_kb = 1024;   // maps smaller than this leave by blocking copies whatever host_stream says
+    long opt_host_min_kb = FC_HOST_MIN_KB;   // maps smaller than this leave by blocking copies whatever host_stream says
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
     long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
     long opt_host_slots = 0;       // ring chunks (0 = auto)
@@ -498,12 +522,13 @@ int ring_ensure(fftconv_plan* p) {
         e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventBlockingSync);
         if (e == hipSuccess) r->landed.push_back(ev);
     }
+    if (e == hipSuccess) e = r->prepare_workers(nthreads);
     if (e != hipSuccess) {
         r->shutdown();
         delete r;
         return fail(FFTCONV_ERR_HIP, "host-output ring setup failed: %s", hipGetErrorString(e));
     }
-    for (int i = 0; i < nthreads; i++) r->workers.emplace_back([r] { r->work(); });
+    for (int i = 0; i < nthreads; i++) r->workers.emplace_back([r, i] { r->work(i); });
     p->ring = r;
     return 0;
 }
