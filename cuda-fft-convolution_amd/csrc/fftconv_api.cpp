@@ -507,6 +507,10 @@ int ring_ensure(fftconv_plan* p) {
     r->chunk_bytes = chunk;
     r->nslots = nslots;
     r->busy.assign(nslots, 0);
+    // one plan at a time in the whole process sets its ring up (streams, events, pinned memory): the per-device
+    // threads of fftconv_multi_convolve each do this on their plan's first host-output call
+    static std::mutex setup_mutex;
+    std::lock_guard<std::mutex> setup_lock(setup_mutex);
     hipError_t e = hipSuccess;
     if (nslots > 0) {
         e = hipHostMalloc(reinterpret_cast<void**>(&r->base), chunk * nslots, hipHostMallocDefault);
