@@ -9,7 +9,7 @@ OBJ=/tmp/fc_variant_$NAME
 mkdir -p $OBJ $ROOT/cuda-fft-convolution_amd/ab
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function $*"
 pids=""
-for f in kernels kernels_rows kernels_rows_multi kernels_rows_multi_f kernels_cols kernels_cols_fwd; do
+for f in kernels kernels_rows kernels_rows_multi kernels_cols kernels_cols_fwd; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o & pids="$pids $!"
 done
 /opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_api.cpp -o $OBJ/fftconv_api.o & pids="$pids $!"
