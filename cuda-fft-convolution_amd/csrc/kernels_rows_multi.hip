@@ -14,6 +14,9 @@ __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_multi(FastRowsArgs a, 
     fast_rows_multi_body<Cfg, NZ2, LINEAR>(ctx, reinterpret_cast<c32*>(fc_smem), a, group, kernel0, nk, rows);
 }
 
+// (Keep the F > 1 kernels in THIS translation unit: compiled in one of their own -- tried for the build time --
+// the same source comes out with 49 instead of 27 spilled registers at L = 4224 and the row kernel 20 % slower at
+// F = 2 ... 8; hipcc -Rpass-analysis=kernel-resource-usage shows it, tools/f_scaling.py measures it.)
 // F > 1: the walk over (map, feature) pairs.  XCD-aware 1-D grid as k_fast_rows' order 2: blocks b and b + 8
 // share an XCD (round-robin dispatch; a speed assumption only), XCD x walks row groups x, x + 8, ... with the
 // walk index fastest, so the workgroups that need the same F image-spectrum rows run side by side on one L2.
