@@ -25,7 +25,12 @@
 #define FC_ROWS_NO_FOLD 0      // 1: A/B, forward stage 1 as a phase of its own for every map
 #endif
 #ifndef FC_ROWSM_DBG
-#define FC_ROWSM_DBG 0         // timing experiments only (wrong results): 1 = P5 without its LDS reads and inverse stage-1 arithmetic (stores + fold only)
+#define FC_ROWSM_DBG 0         // timing experiments only (wrong results): 1 = P5 without its LDS reads and inverse stage-1 arithmetic (stores + fold only); 2 = no stores of the intermediate
+#endif
+#if (FC_ROWSM_DBG & 2)
+#define FC_ROWSM_STORE(ptr, val) do { const ::fc::c32 fc_w_ = (val); if (fc_w_.x == 1.2345e-30f) *(ptr) = fc_w_; } while (0)
+#else
+#define FC_ROWSM_STORE(ptr, val) FC_STREAM_STORE(ptr, val)
 #endif
 #ifndef FC_ROWS_TIMELINE
 #define FC_ROWS_TIMELINE 0     // 1: one workgroup stamps the 100 MHz wall clock at every phase boundary (tools/rows_timeline.py)
@@ -315,12 +320,12 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         if (g.wout >= L) {   // nothing cropped (uniform)
                             static_for<0, R1>([&](auto a_) {
                                 constexpr int a = decltype(a_)::value;
-                                FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                                FC_ROWSM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
                             });
                         } else {             // cropped window (cfg4: 4160 columns of the 4224 transform)
                             static_for<0, R1>([&](auto a_) {
                                 constexpr int a = decltype(a_)::value;
-                                if (j + a * m1 < g.wout) FC_STREAM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                                if (j + a * m1 < g.wout) FC_ROWSM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
                             });
                         }
                         if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read
@@ -357,8 +362,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         constexpr int a = decltype(a_)::value;
                         int w = j + a * m1;
                         if (w < g.wout) {
-                            if (tiled) FC_STREAM_STORE(&yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))], v[a]);
-                            else FC_STREAM_STORE(&yrow[w], v[a]);
+                            if (tiled) FC_ROWSM_STORE(&yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))], v[a]);
+                            else FC_ROWSM_STORE(&yrow[w], v[a]);
                         }
                     });
                     if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read
