@@ -16,6 +16,10 @@ torch.distributed.run the ranks come from the environment.
 `--images n` is BASELINE configs[4]: n images (2048x2048 with --config cfg5) dealt over the ranks,
 every image against all kernels, H2D of the next image behind the compute of the current one.
 
+`--share-gpu` is the rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0 (LOCAL_RANK
+ignored), the collective over gloo (RCCL refuses two ranks on one device) -- rank start-up and teardown,
+per-rank placement tuning, the broadcast step and the timing / check reductions all run as at N > 1.
+
 The steps themselves live in cuda-fft-convolution_amd/multi_gpu.py (shared with the tests).
 
 Untimed set-up and warm-up: for cfg3 / cfg4 the plan times candidate allocations of its intermediate
@@ -75,48 +79,90 @@ def alg_bytes(H, W, F, kh, kw):
 
 
 def host_cores():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota where one is set."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def host_mem_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    return 8 << 30
 
 
 def cpu_baseline(cfg, sample_filters):
     """Times the CPU oracle (port of demoCudaConvolutionFFT.m:78-102, complex128 full transforms)
-    on this host on a bounded sample of the same workload, plus two numbers beside it: the fp32
-    half-spectrum C++ restatement (oracle/fftconv_cpu_f32.cpp) and SciPy's pocketfft.
+    on this host on a bounded sample of the same workload -- one filter per thread on every core this
+    process may use (capped by the filter count, by `sample_filters` when > 0 and by free memory: the
+    float64 port holds ~5 full complex planes per thread) -- plus figures beside it: the same port on 8
+    threads (the figure of earlier rounds), the fp32 half-spectrum C++ restatement
+    (oracle/fftconv_cpu_f32.cpp) and SciPy's pocketfft.
     Returns (json object, oracle maps of the first filters for the self-check)."""
     import util
-    H, W, F, kh, kw, _, seed = CONFIGS[cfg]
+    H, W, F, kh, kw, nf_cfg, seed = CONFIGS[cfg]
     orc = util.Oracle()
     avail = host_cores()
     total = os.cpu_count() or avail
-    threads = max(1, min(sample_filters, avail))
+    fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+    P = fh * fw
+    mem = host_mem_available()
+    per_thread_f64 = 5 * 16 * P * max(1, F)          # complex128 planes a thread of the port holds
+    cap_mem = max(1, int(0.5 * mem / per_thread_f64))
+    threads = max(1, min(nf_cfg, avail, cap_mem, sample_filters if sample_filters > 0 else 64))   # at most 64: the sample stays ~10-30 s and < 100 GB
     n = threads
-    img, ks = util.synth(seed, H, W, F, kh, kw, n)
+    img, ks = util.synth(seed, H, W, F, kh, kw, max(n, min(8, nf_cfg)))
     t0 = time.perf_counter()
-    ref = orc.conv_fft(img, kh, kw, ks, threads=threads)
+    ref = orc.conv_fft(img, kh, kw, ks[:n], threads=threads)
     dt = time.perf_counter() - t0
-    P = ceil16(H + kh - 1) * ceil16(W + kw - 1)
+    ref = ref[:8]       # the self-check compares the first maps only
     res = {"value": n * P / dt / 1e9, "unit": "Gpixel-filters/s", "cores": threads,
            "kind": "port",
-           "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters: %d of the host's %d "
-                     "cores, %d usable by this process), %.1f s wall" % (cfg, n, threads, total, avail, dt)}
+           "sample": "%s image + %d of its filters (float64 fft2/ifft2 oracle, OpenMP over filters: %d threads; the host has %d "
+                     "cores, %d usable by this process, memory allows %d threads), %.1f s wall" % (cfg, n, threads, total, avail, cap_mem, dt)}
+    if threads > 8:     # the 8-thread figure earlier rounds reported
+        t0 = time.perf_counter()
+        orc.conv_fft(img, kh, kw, ks[:8], threads=8)
+        dt8 = time.perf_counter() - t0
+        res["port_8_threads"] = {"value": 8 * P / dt8 / 1e9, "unit": "Gpixel-filters/s", "cores": 8,
+                                 "sample": "same image + 8 filters, %.1f s wall" % dt8}
     # beside the port (SURVEY 8(d)): the same maths in fp32 with half spectra, C++ / OpenMP over filters
     try:
         c32 = util.CpuF32()
+        per_thread_f32 = 4 * 8 * P * max(1, F)
+        th32 = max(1, min(nf_cfg, avail, int(0.5 * mem / per_thread_f32), sample_filters if sample_filters > 0 else 64))
+        _, ks32 = (img, ks) if th32 <= len(ks) else util.synth(seed, H, W, F, kh, kw, th32)
         t0 = time.perf_counter()
-        c32.conv_fft(img, kh, kw, ks, threads=threads)
+        c32.conv_fft(img, kh, kw, ks32[:th32], threads=th32)
         dt1 = time.perf_counter() - t0
-        res["f32_rfft2_port"] = {"value": n * P / dt1 / 1e9, "unit": "Gpixel-filters/s", "cores": threads,
-                                 "sample": "same image + %d filters, fp32 rfft2/irfft2 restatement, %.1f s wall" % (n, dt1)}
+        res["f32_rfft2_port"] = {"value": th32 * P / dt1 / 1e9, "unit": "Gpixel-filters/s", "cores": th32,
+                                 "sample": "same image + %d filters, fp32 rfft2/irfft2 restatement, %d threads, %.1f s wall" % (th32, th32, dt1)}
     except Exception as e:   # optional
         res["f32_rfft2_port"] = {"error": str(e)}
     # ... and on a production CPU FFT: SciPy's pocketfft, float32 rfft2 / irfft2, every usable core --
     # the closest stand-in for MATLAB's multithreaded fft2 / ifft2 on this host (image spectrum once)
     try:
         import scipy.fft as sfft
-        fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
         D = sfft.rfft2(img, s=(fh, fw), axes=(0, 1), workers=avail)   # untimed warm-up of the plan cache
         t0 = time.perf_counter()
         D = sfft.rfft2(img, s=(fh, fw), axes=(0, 1), workers=avail)
@@ -180,7 +226,8 @@ def main():
                          "tune_placement; -1 = 3 where a launch covers >= 5e8 padded pixels, else off; 0 = off)")
     ap.add_argument("--rows-group", type=int, default=0, help="maps per workgroup of the spectral-row kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="filters (= threads) of the CPU baseline sample; 0 = one per usable core, capped by the filter count and by memory")
     ap.add_argument("--check", action="store_true",
                     help="also verify three maps of every rank against the oracle (the cheap all-maps checksum always runs)")
     ap.add_argument("--images", type=int, default=0,
@@ -199,6 +246,12 @@ def main():
                     help="exactly W warm-up steps even when they are shorter than the GPU's clock ramp (A/B)")
     ap.add_argument("--no-live-profile", action="store_true",
                     help="do not time the dominant kernel inside the timed region (roofline from the separate pass only; A/B)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on one GPU: every rank on cuda:0, collective over gloo")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="torch.distributed backend (default: nccl = RCCL over xGMI; gloo with --share-gpu)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra passes (kernel-upload-inclusive steps, default-options plan): A/B runs")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -218,13 +271,22 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if args.share_gpu:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants cuda:%d but this box has %d GPU(s); --share-gpu rehearses the "
+                         "N > 1 path on one GPU" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_collective
+    backend = args.backend or ("gloo" if args.share_gpu else "nccl")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     fc = util.load_package()
     import importlib
@@ -369,7 +431,7 @@ def main():
     # the sum over the whole window of a linear convolution is sum(image) * sum(kernel)
     chk_img = img_d
     if streamed and n_img:
-        chk_img = conv.buf[(n_img - 1) & 1]       # the maps in `out` belong to the last image of the step
+        chk_img = conv.buf[conv.last_buf]         # the maps in `out` belong to the image convolved last
     check = {"checksum_max_rel_err": 0.0}
     if nf and (not streamed or n_img):
         s_img = chk_img.sum(dim=(1, 2), dtype=torch.float64)                        # [F]
@@ -392,6 +454,45 @@ def main():
     torch.cuda.synchronize(dev)
     prof = plan.profile(reset=True)
     plan.set_option("profile", 0)
+
+    # Extra, untimed-for-the-headline passes (N = 1, plain steps only):
+    #  * the same K steps with the kernels uploaded from (pinned) host memory inside every step -- SURVEY 8(d) counts
+    #    the kernel H2D (63 KB each) in the timed region; the headline keeps the kernels resident as the maps are;
+    #  * the same K steps on a second plan with DEFAULT options (no placement tuning) writing into the same maps.
+    extras = {}
+    if world == 1 and not use_dist and not streamed and graph is None and not args.no_extras and nf:
+        kern_pin = torch.from_numpy(kern_h).pin_memory()
+
+        def timed(fn, k):
+            fn(max(1, min(k, 3)))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fn(k)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t1
+
+        def steps_h2d(k):
+            for _ in range(k):
+                kern_d.copy_(kern_pin, non_blocking=True)     # on the plan's stream, ahead of the step that reads them
+                conv.run([img_d])
+
+        dt_h2d = timed(steps_h2d, args.steps)
+        extras["ms_per_step_incl_kernel_h2d"] = dt_h2d / args.steps * 1e3
+        extras["value_incl_kernel_h2d"] = nf_total * P * args.steps / dt_h2d / 1e9
+        if tune_k > 1:
+            plan2 = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream)
+            if args.batch_maps:
+                plan2.set_option("batch_maps", args.batch_maps)
+            eng2 = mg.HipPlanEngine(torch, fc, plan2, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap, out=out)
+            conv2 = mg.FilterShardedConvolver(eng2, None, rank, world, nf_total, src=0, depth=2 if overlap else 1)
+            conv2.run([img_d] * max(2, args.warmup))
+            dt2 = timed(lambda k: conv2.run([img_d] * k), args.steps)
+            extras["value_default_options"] = nf_total * P * args.steps / dt2 / 1e9
+            extras["ms_per_step_default_options"] = dt2 / args.steps * 1e3
+            torch.cuda.synchronize(dev)
+            plan2.destroy()
+        conv.run([img_d])      # `out` holds this plan's maps again for the checks below
+        torch.cuda.synchronize(dev)
 
     result = None
     errs = []
@@ -439,6 +540,7 @@ def main():
         dom = max(per, key=lambda k: per[k]["avg_ms"] / per[k]["units_per_launch"]) if per else None
         traffic = None
         traffic_src = None
+        physical_per_map = None      # PMC bytes of both hot kernels per map (FETCH x 2 + WRITE, profiles/traffic.json)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if dom and os.path.exists(tpath):
             try:
@@ -446,6 +548,8 @@ def main():
                 per_map = tj.get(cfg, {}).get(dom)
                 traffic = per_map * per[dom]["units_per_launch"] if per_map else None
                 traffic_src = tj.get("_source")
+                if all(tj.get(cfg, {}).get(k) for k in ("spectral_rows", "cols_c2r")):
+                    physical_per_map = tj[cfg]["spectral_rows"] + tj[cfg]["cols_c2r"]
             except Exception:
                 traffic = None
         total_maps = (nf_total * args.images) if streamed else nf_total
@@ -478,6 +582,10 @@ def main():
                                       ("filters x%d + 1 bcast per step" % world if world > 1 else "single GPU")},
             "hbm_algorithmic_gbps": ab["total"] * total_maps * args.steps / dt / 1e9,
             "hbm_frac_of_peak": ab["total"] * total_maps * args.steps / dt / 1e9 / (HBM_PEAK_GBPS * world),
+            # what the memory system really moved (PMC counters of an earlier profiled run of this configuration): the
+            # row kernel re-uses the image-spectrum row from registers, so this is BELOW the algorithmic figure
+            "hbm_physical_gbps": (physical_per_map * total_maps * args.steps / dt / 1e9) if physical_per_map else None,
+            "hbm_physical_frac": (physical_per_map * total_maps * args.steps / dt / 1e9 / (HBM_PEAK_GBPS * world)) if physical_per_map else None,
             "kernels": per,
             "image_ms": (prof["image_cols"]["ms"] + prof["image_rows"]["ms"]) / max(1, prof["image_cols"]["launches"]),
             "check_max_rel_err": oracle_err,
@@ -490,6 +598,9 @@ def main():
                                   "traffic_source": traffic_src,
                                   "algorithmic_bytes_per_launch": ab[dom] * per[dom]["units_per_launch"],
                                   "avg_launch_ms": per[dom]["avg_ms"]}
+        result.update(extras)
+        if use_dist:
+            result["config"]["backend"] = backend + (" (all ranks on cuda:0: rehearsal)" if args.share_gpu else "")
         if cpu is not None:
             result["cpu_baseline"] = cpu
     if use_dist:

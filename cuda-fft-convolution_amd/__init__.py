@@ -88,7 +88,7 @@ EXPORTED_SYMBOLS = (
     "fftconv_plan_synchronize", "fftconv_plan_set_stream",
     "fftconv_plan_set_option", "fftconv_plan_get_option", "fftconv_plan_get_profile", "fftconv_fft_data", "fftconv_conv_fft_data",
     "fftconv_multi_create", "fftconv_multi_destroy", "fftconv_multi_set_image", "fftconv_multi_import_spectrum",
-    "fftconv_multi_convolve",
+    "fftconv_multi_convolve", "fftconv_multi_set_option", "fftconv_multi_get_option",
     "fftconv_multi_shard", "fftconv_multi_size", "fftconv_multi_plan", "fftconv_convolution_fft_multi",
 )
 
@@ -161,6 +161,8 @@ def load_library():
     lib.fftconv_multi_set_image.argtypes = [vp, vp, ci]
     lib.fftconv_multi_import_spectrum.argtypes = [vp, vp, ci]
     lib.fftconv_multi_convolve.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci]
+    lib.fftconv_multi_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
+    lib.fftconv_multi_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]
     lib.fftconv_multi_shard.argtypes = [vp, ci, ci, pi, pi]
     lib.fftconv_multi_size.argtypes = [vp]
     lib.fftconv_multi_plan.argtypes = [vp, ci, ctypes.POINTER(vp), pi]
@@ -412,6 +414,8 @@ class MultiPlan:
         oref, _okeep = _options_ptr(options)
         _check(self._lib.fftconv_multi_create(ctypes.byref(self._h), int(H), int(W), int(F), int(maxKernelH), int(maxKernelW),
                                               devs, len(gpuIds), oref))
+        # "" or the warning naming destinations without direct peer access to gpuIds[0] (their copies are staged)
+        self.warning = (self._lib.fftconv_last_error() or b"").decode()
         self.shape = (int(H), int(W), int(F))
         p, dev = ctypes.c_void_p(None), ctypes.c_int(0)
         _check(self._lib.fftconv_multi_plan(self._h, 0, ctypes.byref(p), ctypes.byref(dev)))
@@ -420,6 +424,19 @@ class MultiPlan:
 
     def __len__(self):
         return self._lib.fftconv_multi_size(self._h)
+
+    def set_option(self, name, value):
+        """"spectrum_transport" 0 peer copies / 1 one RCCL broadcast; "verbose" (include/fftconv.h)"""
+        _check(self._lib.fftconv_multi_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_long(0)
+        _check(self._lib.fftconv_multi_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def last_message(self):
+        """text of the calling thread's last error / warning (e.g. why the RCCL transport was not used)"""
+        return (self._lib.fftconv_last_error() or b"").decode()
 
     def shard(self, n_kernel, index):
         first, count = ctypes.c_int(0), ctypes.c_int(0)

@@ -357,12 +357,13 @@ struct fftconv_plan {
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
     long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
     long opt_host_slots = 0;       // ring chunks (0 = auto)
+    long opt_verbose = 0;          // 1: per-stage sizes and launch shapes to stderr (the reference's `debug`, src/cudaConvolutionFFT.cu:9)
     HostRing* ring = nullptr;      // created on the first host-output convolve
     bool profile = false;
     unsigned profile_mask = ~0u;   // which kinds (bit = PK_* index) are timed while `profile` is on
     bool prof_open = false;        // the last prof_begin recorded a start event
     // kernel column spectra of the first chunk already in A (fftconv_plan_prepare_kernels_packed)
-    struct { const float* dk = nullptr; int n = 0, kh = 0, kw = 0; } prepared;
+    struct { const float* dk = nullptr; int n = 0, kh = 0, kw = 0; hipStream_t stream = nullptr; } prepared;   // (stream: the one A was produced on)
     std::vector<EventPair> pending;
     std::vector<EventPair> pool;
     double prof_ms[PK_COUNT] = {0, 0, 0, 0, 0};
@@ -430,6 +431,9 @@ struct fftconv_plan {
 };
 
 namespace {
+
+// the reference's debug prints (src/cudaConvolutionFFT.cu:60,68,100,114,240,258), behind plan option "verbose"
+#define FC_VERBOSE(p, ...) do { if ((p)->opt_verbose) { fprintf(stderr, "fftconv: " __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
 int use_device(const fftconv_plan* p) {
     HIP_TRY(hipSetDevice(p->gpu_id));
@@ -619,6 +623,11 @@ int tune_intermediate_placement(fftconv_plan* p, int n, int nbY, float* out, siz
     const int k = (int)p->opt_tune_placement;
     p->Y.fresh = false;
     if (k < 2 || !g.fast_cols.ok || n < 1) return 0;
+    {   // the tuner synchronises and frees: not inside a stream capture (the first convolve of a graph keeps its allocation)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(p->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) return 0;
+    }
     const int nbatch = out_stride_per_map ? std::min(16, (n + nbY - 1) / nbY) : 1;
     std::vector<DevBuf<c32>> cand((size_t)k);
     cand[0] = p->Y;
@@ -642,6 +651,10 @@ int tune_intermediate_placement(fftconv_plan* p, int n, int nbY, float* out, siz
         cand[nc].cap = cand[0].cap;
     }
     for (void* sp : spacers) (void)hipFree(sp);
+    // every candidate reads the same contents (zeros): recycled allocations may hold anything, and what is timed
+    // must be the placement, not NaNs or denormals in one of them (transient peak: k intermediates + the spacers)
+    for (int c = 0; c < nc; c++)
+        if (hipMemsetAsync(cand[c].p, 0, cand[c].cap * sizeof(c32), p->stream) != hipSuccess) (void)hipGetLastError();
     auto launch = [&](const DevBuf<c32>& y) -> hipError_t {   // the output launches of the whole call
         for (int b = 0; b < nbatch; b++) {
             const int ny = std::min(nbY, n - b * nbY);
@@ -703,6 +716,9 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     const BatchSizes bs = batch_sizes(p, n, kw);
     const size_t per_a = bs.per_a;
     const int nbY = bs.nbY, nbA = bs.nbA;
+    FC_VERBOSE(p, "Kernel size: h=%d, w=%d", kh, kw);                 // src/cudaConvolutionFFT.cu:240
+    FC_VERBOSE(p, "N Kernel: %d (maps per launch %d, kernels per column-spectrum chunk %d, %s)", n, nbY, nbA,
+               sink.packed ? "packed device output" : sink.location == FFTCONV_HOST ? "host output" : "device output");   // :68
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
     const bool staged = (sink.packed == nullptr);
@@ -741,12 +757,16 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     const int cthreads = cols_threads(g), rthreads = rows_threads(g);
     for (int a0 = 0; a0 < n; a0 += nbA) {
         const int na = std::min(nbA, n - a0);
-        const bool have_cols = (a0 == 0 && p->prepared.dk == dk && p->prepared.n == n && p->prepared.kh == kh && p->prepared.kw == kw);
+        const bool have_cols = (a0 == 0 && p->prepared.dk == dk && p->prepared.n == n && p->prepared.kh == kh && p->prepared.kw == kw &&
+                                p->prepared.stream == p->stream);
         p->prepared.dk = nullptr;   // A is about to be consumed / overwritten
         if (!have_cols)
             if (int rc = launch_kernel_cols(p, dk, a0, na, kh, kw)) return rc;
         for (int y0 = 0; y0 < na; y0 += nbY) {
             const int ny = std::min(nbY, na - y0);
+            FC_VERBOSE(p, "maps %d..%d: spectral rows (%s, %d rows x %d points, %d maps per workgroup), output columns (%s, %d-point, %d columns per tile)",
+                       a0 + y0, a0 + y0 + ny - 1, g.fast_rows.ok ? "specialised" : "generic", g.rows, g.Lw, g.rows_group_for(ny, p->num_cus),
+                       g.fast_cols.ok ? "specialised" : "generic", g.M, g.fast_cols.ok ? g.fast_cols.T : g.T_cols);
             if (int rc = p->prof_begin(PK_SPECTRAL, ny)) return rc;
             if (g.rows_group_for(ny, p->num_cus) > 1) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
@@ -802,6 +822,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
         hipError_t e = p->ring->wait_idle();
         if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "host-output copy failed: %s", hipGetErrorString(e));
     }
+    FC_VERBOSE(p, "FFT done");                                        // src/cudaConvolutionFFT.cu:258
     return 0;
 }
 
@@ -1067,6 +1088,10 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         HIP_TRY(hipMemcpyAsync(p->I.p, data, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
         dimg = p->I.p;
     }
+    FC_VERBOSE(p, "Using GPU : %d", p->gpu_id);                                                    // src/cudaConvolutionFFT.cu:87
+    FC_VERBOSE(p, "Data size: h=%d, w=%d, f=%d", g.H, g.W, g.F);                                   // :100
+    FC_VERBOSE(p, "FFT size: h=%d, w=%d (internal transform %d x %d, %s column pass, %s row pass, %s intermediate)", g.fft_h, g.fft_w, g.Lh, g.Lw,   // :114
+               g.fast_fwd ? "specialised" : "generic", g.fast_rows.ok ? "specialised" : "generic", g.y_tiled() ? "tiled" : "row-major");
     // (with the fast row kernel the w-pass stores the spectrum directly in that kernel's register order)
     if (int rc = p->ensure_spectrum()) return rc;
     c32* sgen = p->spec();
@@ -1186,6 +1211,7 @@ int fftconv_plan_prepare_kernels_packed(fftconv_plan* plan, int n_kernel, const 
     p->prepared.dk = nullptr;
     if (int rc = launch_kernel_cols(p, kernels_device, 0, std::min(bs.nbA, n_kernel), kernel_h, kernel_w)) return rc;
     p->prepared.dk = kernels_device; p->prepared.n = n_kernel; p->prepared.kh = kernel_h; p->prepared.kw = kernel_w;
+    p->prepared.stream = p->stream;
     return 0;
 }
 
@@ -1231,8 +1257,9 @@ int fftconv_plan_set_stream(fftconv_plan* plan, void* hip_stream) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     // (profile events already recorded stay valid: they are read later by fftconv_plan_get_profile,
     //  whichever stream they were recorded on -- collecting them here would block the host)
+    // (prepared column spectra stay: they count again once the plan is back on the stream they were produced on --
+    //  the image transform of the multi-GPU step borrows the plan for a side stream and hands it back)
     plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
-    plan->prepared.dk = nullptr;
     return 0;
 }
 
@@ -1249,6 +1276,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "verbose")) { plan->opt_verbose = value != 0; return 0; }
     if (!strcmp(name, "profile_kinds")) { plan->profile_mask = value <= 0 ? ~0u : (unsigned)value; return 0; }
     if (!strcmp(name, "rows_group")) { plan->g.rows_group = value <= 0 ? -1 : (int)value; return 0; }
 #if FC_ROWS_TIMELINE || FC_COLS_TIMELINE
@@ -1302,6 +1330,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "output_region")) { *value = plan->opt_region; return 0; }
     if (!strcmp(name, "flip_kernels")) { *value = plan->opt_flip_kernels; return 0; }
     if (!strcmp(name, "profile")) { *value = plan->profile ? 1 : 0; return 0; }
+    if (!strcmp(name, "verbose")) { *value = plan->opt_verbose; return 0; }
     return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 

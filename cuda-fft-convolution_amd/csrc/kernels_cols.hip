@@ -23,7 +23,7 @@ struct FastColsLauncher {
     }
     template <class Cfg, bool TILED>
     void launch() {
-        static unsigned long long attr_mask = 0;
+        static LdsAttrMask attr_mask{0};
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
         err = ensure_lds_attr(k_fast_cols<Cfg, TILED>, attr_mask);
         if (err != hipSuccess) return;

@@ -18,7 +18,7 @@ struct FastColsFwdLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg, int NZ2>
     void go() {
-        static unsigned long long attr_mask = 0;
+        static LdsAttrMask attr_mask{0};
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
         err = ensure_lds_attr(k_fast_cols_fwd<Cfg, NZ2>, attr_mask);
         if (err != hipSuccess) return;

@@ -3,6 +3,7 @@
 // the per-device LDS attribute helper.  (The kernels are split over several translation units
 // only so that they compile in parallel.)
 #pragma once
+#include <atomic>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -14,15 +15,17 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
 
 // Raises the dynamic-LDS limit of a kernel once per device (the attribute is per device; a
 // process may drive several GPUs through different plans).
+// (the per-device threads of fftconv_multi_convolve come through here at the same time: the mask is atomic)
+using LdsAttrMask = std::atomic<unsigned long long>;
 template <class K>
-hipError_t ensure_lds_attr(K kernel, unsigned long long& done_mask) {
+hipError_t ensure_lds_attr(K kernel, LdsAttrMask& done_mask) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
-    if (done_mask & bit) return hipSuccess;
+    if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) done_mask |= bit;
+    if (e == hipSuccess) done_mask.fetch_or(bit, std::memory_order_release);
     return e;
 }
 

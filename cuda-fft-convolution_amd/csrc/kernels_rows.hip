@@ -45,7 +45,7 @@ struct FastRowsLauncher {
     }
     template <class Cfg, int NZ2, bool MULTIF>
     void launch() {
-        static unsigned long long attr_mask = 0;
+        static LdsAttrMask attr_mask{0};
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
         err = ensure_lds_attr(k_fast_rows<Cfg, NZ2, MULTIF>, attr_mask);
         if (err != hipSuccess) return;
@@ -71,7 +71,7 @@ struct FastRowsFwdLauncher {
     hipError_t err = hipSuccess;
     template <class Cfg>
     void go() {
-        static unsigned long long attr_mask = 0;
+        static LdsAttrMask attr_mask{0};
         const size_t lds = (size_t)Cfg::LDS_ELEMS * sizeof(c32);
         err = ensure_lds_attr(k_fast_rows_fwd<Cfg>, attr_mask);
         if (err != hipSuccess) return;

@@ -50,13 +50,13 @@ struct FastRowsMultiLauncher {
         const int groups = (rows + Cfg::RPW - 1) / Cfg::RPW;
         const int walks = (kernels + per_wg - 1) / per_wg;
         if (a.F > 1) {
-            static unsigned long long attr_mask_f = 0;
+            static LdsAttrMask attr_mask_f{0};
             err = ensure_lds_attr(k_fast_rows_multi_f<Cfg, NZ2, LINEAR>, attr_mask_f);
             if (err != hipSuccess) return;
             const dim3 grid(8 * ((groups + 7) / 8) * walks);
             hipLaunchKernelGGL((k_fast_rows_multi_f<Cfg, NZ2, LINEAR>), grid, dim3(Cfg::NT), lds, s, a, rows, kernels, per_wg, groups, walks);
         } else {
-            static unsigned long long attr_mask = 0;
+            static LdsAttrMask attr_mask{0};
             err = ensure_lds_attr(k_fast_rows_multi<Cfg, NZ2, LINEAR>, attr_mask);
             if (err != hipSuccess) return;
             const dim3 grid(groups, walks);

@@ -176,6 +176,8 @@ class ImageStreamedConvolver:
         s = engine.sync
         self.copied = [s.event() for _ in range(2)]
         self.consumed = [s.event() for _ in range(2)]   # the image transform that read buffer b is done
+        self.n_run = 0          # images convolved so far (over all run() calls): image i uses buffer i & 1
+        self.last_buf = None    # index of the device buffer holding the image convolved last
 
     def _upload(self, b, host_image):
         s = self.engine.sync
@@ -188,10 +190,11 @@ class ImageStreamedConvolver:
         host_images = list(host_images)
         s = self.engine.sync
         last = None
+        base = self.n_run & 1       # continue the alternation across calls (the events order the reuse either way)
         if host_images:
-            self._upload(0, host_images[0])
+            self._upload(base, host_images[0])
         for i in range(len(host_images)):
-            b = i & 1
+            b = (base + i) & 1
             if i + 1 < len(host_images):
                 self._upload(1 - b, host_images[i + 1])   # next image's H2D while this one is convolved
             prep = getattr(self.engine, "prepare_kernels", None)
@@ -201,8 +204,10 @@ class ImageStreamedConvolver:
             self.engine.compute_spectrum(self.spec, self.buf[b])
             s.record(self.consumed[b])
             last = self.engine.convolve(self.spec, 0, self.n_filters)
+            self.last_buf = b
             if on_result is not None:
                 on_result(i, last)
+        self.n_run += len(host_images)
         return last
 
 
@@ -211,7 +216,7 @@ class HipPlanEngine:
     torch tensors for memory and streams.  `kernels` is this rank's block, packed [n][F][kw][kh];
     convolve() returns the device tensor [n][FFT_W][FFT_H] it fills (reused by every call)."""
 
-    def __init__(self, torch, fc, plan, device, kernels, kh, kw, first=0, main_stream=None, overlap=True):
+    def __init__(self, torch, fc, plan, device, kernels, kh, kw, first=0, main_stream=None, overlap=True, out=None):
         self.torch, self.fc, self.plan, self.device = torch, fc, plan, device
         self.kernels, self.kh, self.kw, self.first = kernels, kh, kw, first
         self.count = int(kernels.shape[0])
@@ -221,7 +226,8 @@ class HipPlanEngine:
         # without it everything is queued on the plan's stream in program order (no events needed)
         self.sync = TorchStreamSync(torch, device, self.main_stream) if overlap else NullSync()
         info = plan.info
-        self.out = torch.empty((max(1, self.count), info.fft_w, info.fft_h), dtype=torch.float32, device=device)
+        # `out`: reuse another engine's map buffer (bench.py times a second, default-options plan into the same maps)
+        self.out = out if out is not None else torch.empty((max(1, self.count), info.fft_w, info.fft_h), dtype=torch.float32, device=device)
         self._keep = None
 
     def new_spectrum(self):

@@ -264,6 +264,8 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             per dimension, the window the reference's unused computeFFTsize would give
  *             (src/cudaConvFFTData.h:67-94): the convolution in its top-left corner, zeros elsewhere.
  *             Result buffers then hold out_h x out_w floats (fftconv_plan_get_info)),
+ *          "verbose" (1: the sizes and launch shapes of every stage go to stderr as the work is queued -- the
+ *             reference's compile-time `debug` switch, src/cudaConvolutionFFT.cu:9,60,100,114,240,258; 0 (default) silent),
  *          "flip_kernels" (1: every kernel is flipped along h and w on the device before it is
  *             transformed, i.e. the plan correlates -- the "Flip Kernel (Required)" step of
  *             demoCudaConvolutionFFT.m:63-69 done here instead of in MATLAB; the reference keeps a
@@ -315,6 +317,17 @@ int fftconv_multi_create(fftconv_multi **multi, int data_h, int data_w, int feat
                          int max_kernel_h, int max_kernel_w, const int *devices, int n_devices,
                          const fftconv_plan_options *options);
 int fftconv_multi_destroy(fftconv_multi *multi);
+/* After a successful fftconv_multi_create, fftconv_last_error() is "" -- or a warning naming the devices that have
+ * no direct (xGMI peer) access to devices[0]: copies to those are staged by the runtime (slower, still correct).
+ * Options: "spectrum_transport" 0 (default) = the reference's form, one peer copy per destination
+ *             (src/cudaConvFFTDataStreams.cu:282-287); 1 = ONE collective: ncclBroadcast of the spectrum buffer over a
+ *             communicator of the listed devices (RCCL over xGMI; librccl.so is loaded on first use, the devices must
+ *             be distinct).  Where RCCL cannot be set up the copies are used and fftconv_last_error() says why;
+ *          "verbose" 1 = what happens, to stderr (also sets every plan's "verbose").
+ * Read-only: "transport_used" (what the last set_image / import_spectrum used), "peer_direct" (destinations with
+ * direct access to devices[0]). */
+int fftconv_multi_set_option(fftconv_multi *multi, const char *name, long value);
+int fftconv_multi_get_option(const fftconv_multi *multi, const char *name, long *value);
 /* padData + cufftExecR2C of the image on devices[0] (src/cudaConvolutionFFT.cu:144-169), then the
  * peer copies.  location FFTCONV_HOST, or FFTCONV_DEVICE for memory of devices[0]. */
 int fftconv_multi_set_image(fftconv_multi *multi, const float *data, int location);

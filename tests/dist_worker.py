@@ -4,8 +4,8 @@ rank's maps to FC_OUT/rank<r>.npz.
 
 FC_ENGINE = emu   host emulator of the kernel bodies as engine (CPU tier, gloo)
           = hip   HIP plans as engines, every rank on cuda:0 (GPU tier: two processes share the one
-                  test GPU, gloo moves the spectrum; on a multi-GPU node bench.py does the same
-                  over RCCL with one GPU per rank)
+                  test GPU, gloo moves the spectrum)
+          = hip_nccl  HIP plans, rank r on cuda:r, the broadcast over RCCL ("nccl"): needs >= world GPUs
 FC_CASE   = H,W,F,kh,kw,N,n_images   problem (seeded like util.synth)
 """
 import ctypes
@@ -80,16 +80,23 @@ def to_host_maps(res, count):
 
 def main():
     engine_kind = os.environ.get("FC_ENGINE", "emu")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gpu = 0
+    if engine_kind == "hip_nccl":      # one GPU per rank, RCCL: what bench.py does on a multi-GPU node
+        gpu = rank
+        torch.cuda.set_device(gpu)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
+        engine_kind = "hip"
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     saved = {}
 
     # ---- filter sharding: NIMG distinct images one after the other (pipelined: two spectrum buffers)
     first, count = mg.filter_shard(N, rank, world)
     if engine_kind == "hip":
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", gpu)
         torch.cuda.set_device(dev)
         stream = torch.cuda.current_stream(dev)
-        plan = fc.Plan(H, W, F, kh, kw, gpuId=0, stream=stream.cuda_stream)
+        plan = fc.Plan(H, W, F, kh, kw, gpuId=gpu, stream=stream.cuda_stream)
         kern = np.stack([np.transpose(KS[first + j], (2, 1, 0)) for j in range(count)]) if count else np.zeros((0, F, kw, kh), np.float32)
         kern_d = torch.from_numpy(np.ascontiguousarray(kern)).to(dev)
         engine = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=first, main_stream=stream)

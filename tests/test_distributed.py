@@ -109,6 +109,45 @@ def test_convolver_refuses_to_overwrite_an_unconsumed_spectrum():
     assert c.run(["x", "y", "z"]) == "z"
 
 
+def test_streamed_convolver_remembers_the_buffer_of_the_last_image():
+    """bench.py checks the maps of the LAST image a run() convolved: with an odd number of images per call and an
+    even number of calls the device buffer holding it alternates (the self-check of round 2 read the wrong one)"""
+    import importlib
+    mg = importlib.import_module("cuda-fft-convolution_amd.multi_gpu")
+
+    class Eng:
+        sync = mg.NullSync()
+
+        def __init__(self):
+            self.n = 0
+
+        def new_spectrum(self):
+            return [None]
+
+        def new_image_buffer(self):
+            self.n += 1
+            return {"id": self.n, "img": None}
+
+        def upload(self, buf, host_image):
+            buf["img"] = host_image
+
+        def compute_spectrum(self, spec, image):
+            spec[0] = image["img"]
+
+        def convolve(self, spec, first, count):
+            return spec[0]
+
+    for n_img, calls in ((3, 2), (3, 3), (4, 2), (1, 5), (5, 4)):
+        c = mg.ImageStreamedConvolver(Eng(), 2)
+        for call in range(calls):
+            imgs = ["c%d_i%d" % (call, i) for i in range(n_img)]
+            seen = []
+            last = c.run(imgs, on_result=lambda i, r: seen.append(r))
+            assert seen == imgs and last == imgs[-1]                      # every image convolved, in order
+            assert c.buf[c.last_buf]["img"] == imgs[-1], (n_img, calls)   # ... and last_buf names the buffer that holds the last one
+        assert c.n_run == n_img * calls
+
+
 def test_world2_gloo_emulator_matches_oracle(tmp_path, oracle):
     subprocess.run(["make", "-C", os.path.join(util.ROOT, "tests", "emu")], check=True,
                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -169,3 +208,115 @@ def test_bench_steps_self_check(args):
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["check_ok"] and j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
+
+
+def _bench(args, timeout=900):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_bench_streamed_check_reads_the_last_image_odd_images_even_steps():
+    """(advisor, round 2) 3 images per rank and an even step count: the last image of the timed region sits in the
+    OTHER device buffer than after one step; the self-check has to follow it"""
+    for steps in ("2", "3"):
+        j = _bench(["--config", "cfg1", "--images", "3", "--steps", steps, "--warmup", "1", "--check", "--no-cpu-baseline"])
+        assert j["check_ok"] and j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_cfg4_full_size():
+    """Rehearsal of what the driver runs at N > 1, at FULL cfg4 size on the one test GPU: bench.py starts its two ranks
+    itself, both on cuda:0 (--share-gpu: gloo moves the spectrum), each rank tunes its placement, runs the
+    filter-sharded step with the broadcast and two spectrum buffers (64 + 64 kernels of 63 x 63 on the 4096 x 4096
+    image: 4160 windows cropped from 4224 transforms), the timing / check reductions run over the ranks, and three
+    maps of every rank are compared with the oracle"""
+    j = _bench(["--gpus", "2", "--share-gpu", "--config", "cfg4", "--filters", "128", "--steps", "3", "--warmup", "1", "--check",
+                "--no-cpu-baseline"], timeout=1200)
+    assert j["n_gpus"] == 2 and j["check_ok"]
+    assert j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
+    assert j["config"]["filters_total"] == 128 and j["config"]["filters_per_gpu"] == 64
+    assert "gloo" in j["config"]["backend"]
+
+
+@pytest.mark.gpu
+def test_bench_streamed_two_ranks_on_one_gpu_cfg5_full_size():
+    """cfg5's form at full size with two ranks on the one GPU: 2048 x 2048 images streamed (3 per rank over 2 ranks ->
+    6 in total, odd per rank), 64 kernels of 63 x 63 each, no collective on the data path"""
+    j = _bench(["--gpus", "2", "--share-gpu", "--config", "cfg5", "--images", "6", "--steps", "2", "--warmup", "1", "--check",
+                "--no-cpu-baseline"], timeout=1200)
+    assert j["n_gpus"] == 2 and j["check_ok"] and j["scaling"] == "weak"
+    assert j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
+
+
+def _gpu_count():
+    try:
+        return util.load_package().device_count()
+    except Exception:
+        return 0
+
+
+needs_two_gpus = pytest.mark.skipif(_gpu_count() < 2, reason="needs at least two GPUs (the test box has one; the driver's scaling node has eight)")
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+@pytest.mark.parametrize("case", [(300, 260, 1, 63, 63, 9, 3), (512, 512, 1, 31, 31, 7, 3)])
+def test_world_nccl_one_gpu_per_rank_matches_oracle(tmp_path, oracle, case):
+    """the same two convolvers over RCCL ("nccl"), one GPU per rank, as bench.py runs them on a multi-GPU node:
+    every map of every image against the oracle"""
+    world = min(_gpu_count(), 4)
+    ranks = run_world(tmp_path, "hip_nccl", case, world=world)
+    check_world(oracle, ranks, case, 1e-5)
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+def test_bench_nccl_two_gpus_cfg4_share():
+    """bench.py --gpus 2 over RCCL on two GPUs: cfg4's sharded form at full size, checked"""
+    j = _bench(["--gpus", "2", "--config", "cfg4", "--filters", "128", "--steps", "3", "--warmup", "1", "--check", "--no-cpu-baseline"],
+               timeout=1200)
+    assert j["n_gpus"] == 2 and j["check_ok"] and "nccl" in j["config"]["backend"]
+
+
+@pytest.mark.gpu
+@needs_two_gpus
+@pytest.mark.parametrize("transport", [0, 1])
+def test_in_library_multi_device_plan_on_distinct_devices(fftconv, oracle, transport):
+    """fftconv_multi_* over DISTINCT devices: the spectrum really crosses xGMI -- by hipMemcpyPeerAsync (transport 0,
+    src/cudaConvFFTDataStreams.cu:282-287) or by one ncclBroadcast (transport 1, north_star's collective)"""
+    H, W, F, kh, kw, n = 200, 180, 2, 15, 11, 7
+    data, ks = util.synth(71, H, W, F, kh, kw, n)
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    devs = list(range(min(_gpu_count(), 4)))
+    with fftconv.MultiPlan(H, W, F, kh, kw, devs) as mp:
+        assert mp.get_option("peer_direct") == len(devs) - 1, mp.warning
+        mp.set_option("spectrum_transport", transport)
+        for rep in range(2):
+            mp.set_image(data)
+            assert mp.get_option("transport_used") == transport, mp.last_message()
+            for g, r in zip(mp.convolve(ks), ref):
+                assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.gpu
+def test_multi_plan_options_and_rccl_fallback_on_one_gpu(fftconv, oracle):
+    """one GPU listed twice cannot form an RCCL communicator: the broadcast transport falls back to the copies, says
+    why, and the maps are right; peer_direct counts same-device destinations as direct"""
+    H, W, F, kh, kw, n = 120, 100, 1, 9, 9, 4
+    data, ks = util.synth(72, H, W, F, kh, kw, n)
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    with fftconv.MultiPlan(H, W, F, kh, kw, [0, 0]) as mp:
+        assert mp.warning == "" and mp.get_option("peer_direct") == 1
+        mp.set_option("spectrum_transport", 1)
+        mp.set_image(data)
+        assert mp.get_option("transport_used") == 0 and "listed twice" in mp.last_message()
+        for g, r in zip(mp.convolve(ks), ref):
+            assert util.rel_err(g, r) < 1e-5
+        with pytest.raises(fftconv.FFTConvError):
+            mp.set_option("spectrum_transport", 2)
+        with pytest.raises(fftconv.FFTConvError):
+            mp.get_option("no_such_option")

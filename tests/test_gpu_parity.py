@@ -389,6 +389,105 @@ def test_cfg3_headline_launch_geometry(fc, oracle):
         assert util.rel_err(out[j].cpu().numpy().T, r) < TOL
 
 
+def test_cfg4_headline_launch_geometry(fc, oracle):
+    """The launch geometry bench.py times for BASELINE configs[3] (one rank's share, and the 1-GPU denominator):
+    4096x4096 image, 63x63 kernels, 84 kernels in one packed call = a full 64-map launch of the multi-map row
+    kernel (16-map walks) + a 20-map launch, the 4160 x 4160 window CROPPED from the 4224 x 4224 transform (the
+    `wout < L` store branch of the row kernel, the cropped rows of the output kernel).  All maps on the device by
+    checksum identity, delta kernels and linear combinations; three maps across the launch boundary against the
+    oracle (src/cudaConvolutionFFT.cu:204-291 is the loop this batches)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H = W = 4096
+    kh = kw = 63
+    n = 84
+    g = torch.Generator(device="cpu").manual_seed(1234 + 44)
+    img = torch.rand((1, W, H), generator=g, dtype=torch.float32)
+    ks = torch.rand((n, 1, kw, kh), generator=g, dtype=torch.float32)
+    ks[9].zero_(); ks[9, 0, 62, 5] = 1.0                  # delta at (h = 5, w = 62): first launch
+    ks[77].zero_(); ks[77, 0, 1, 62] = 1.0                # delta at (h = 62, w = 1): second launch
+    combos = {33: (2.0, 4, -3.0, 30), 65: (0.5, 63, 1.5, 64), 82: (-1.0, 1, 4.0, 80)}
+    for j, (a, p_, b, q_) in combos.items():
+        ks[j] = a * ks[p_] + b * ks[q_]
+    with fc.Plan(H, W, 1, kh, kw) as p:
+        assert (p.info.fft_h, p.info.fft_w) == (4160, 4160) and (p.info.transform_h, p.info.transform_w) == (4224, 4224)
+    out = _device_run(fc, torch, img.to(dev), ks.to(dev), kh, kw)
+    assert tuple(out.shape) == (n, 4160, 4160)
+    img_d = img.to(dev)
+    s_img = float(img.double().sum())
+    s_ker = ks.double().sum(dim=(1, 2, 3))
+    s_map = out.sum(dim=(1, 2), dtype=torch.float64).cpu()
+    want = s_img * s_ker
+    assert float(((s_map - want).abs() / want.abs()).max()) < 1e-5
+    for j, (dh, dw) in {9: (5, 62), 77: (62, 1)}.items():
+        w_ = torch.zeros((4160, 4160), dtype=torch.float32, device=dev)
+        w_[dw:dw + W, dh:dh + H] = img_d[0]
+        assert float((out[j] - w_).abs().max()) < TOL
+        del w_
+    for j, (a, p_, b, q_) in combos.items():
+        d = (out[j].double() - (a * out[p_].double() + b * out[q_].double())).abs().max()
+        assert float(d) / float(out[j].abs().max()) < TOL
+    scale = float(out.abs().amax())     # nothing outside the linear support (4158 x 4158); here written as exact zeros
+    assert float(out[:, 4158:, :].abs().amax()) / scale < TOL and float(out[:, :, 4158:].abs().amax()) / scale < TOL
+    idx = [15, 63, 64]
+    img_np = np.asfortranarray(np.transpose(img.numpy(), (2, 1, 0)))
+    k_np = [np.asfortranarray(np.transpose(ks[j].numpy(), (2, 1, 0))) for j in idx]
+    ref = oracle.conv_fft(img_np, kh, kw, k_np)
+    for j, r in zip(idx, ref):
+        assert util.rel_err(out[j].cpu().numpy().T, r) < TOL
+
+
+def test_cfg5_headline_streamed_geometry(fc, oracle):
+    """BASELINE configs[4] as bench.py --images runs it on every rank: 2048x2048 images STREAMED from pinned host
+    memory through ImageStreamedConvolver (H2D of image i + 1 on the side stream beside the maps of image i, two
+    device buffers), 64 kernels of 63x63 per image -> 64 maps of 2112 x 2112 in one launch (2112 = 8.12.22, two rows
+    per row workgroup).  Three images; after EACH image every map is checked on the device (checksum identity; a
+    delta kernel = the shifted image; a linear combination), and three maps of the last image go against the oracle."""
+    import importlib
+    torch = pytest.importorskip("torch")
+    mg = importlib.import_module(fc.__name__ + ".multi_gpu")
+    dev = torch.device("cuda", 0)
+    H = W = 2048
+    kh = kw = 63
+    n = 64
+    g = torch.Generator(device="cpu").manual_seed(1234 + 55)
+    imgs = [torch.rand((1, W, H), generator=g, dtype=torch.float32).pin_memory() for _ in range(3)]
+    ks = torch.rand((n, 1, kw, kh), generator=g, dtype=torch.float32)
+    ks[20].zero_(); ks[20, 0, 7, 40] = 1.0               # delta at (h = 40, w = 7)
+    ks[50] = 2.0 * ks[3] - 0.5 * ks[63]
+    kern_d = ks.to(dev)
+    stream = torch.cuda.current_stream(dev)
+    s_ker = ks.double().sum(dim=(1, 2, 3))
+    with fc.Plan(H, W, 1, kh, kw, gpuId=0, stream=stream.cuda_stream) as plan:
+        assert (plan.info.fft_h, plan.info.fft_w) == (2112, 2112)
+        engine = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=0, main_stream=stream, overlap=True)
+        conv = mg.ImageStreamedConvolver(engine, n)
+        seen = []
+
+        def check(i, out):
+            torch.cuda.synchronize(dev)
+            img_d = imgs[i].to(dev)
+            want = float(imgs[i].double().sum()) * s_ker
+            got = out.sum(dim=(1, 2), dtype=torch.float64).cpu()
+            assert float(((got - want).abs() / want.abs()).max()) < 1e-5, i
+            w_ = torch.zeros((2112, 2112), dtype=torch.float32, device=dev)
+            w_[7:7 + W, 40:40 + H] = img_d[0]
+            assert float((out[20] - w_).abs().max()) < TOL, i
+            d = (out[50].double() - (2.0 * out[3].double() - 0.5 * out[63].double())).abs().max()
+            assert float(d) / float(out[50].abs().max()) < TOL, i
+            seen.append(i)
+
+        out = conv.run(imgs, on_result=check)
+        assert seen == [0, 1, 2] and conv.last_buf == 0
+        torch.cuda.synchronize(dev)
+        idx = [0, 31, 63]
+        img_np = np.asfortranarray(np.transpose(imgs[2].numpy(), (2, 1, 0)))
+        k_np = [np.asfortranarray(np.transpose(ks[j].numpy(), (2, 1, 0))) for j in idx]
+        ref = oracle.conv_fft(img_np, kh, kw, k_np)
+        for j, r in zip(idx, ref):
+            assert util.rel_err(out[j].cpu().numpy().T, r) < TOL
+
+
 def test_cfg4_and_cfg5_geometry_vs_oracle(fc, oracle):
     """BASELINE configs[3] (4160x4160 maps, 63x63 kernels) and configs[4] (2048x2048 image ->
     2112x2112): one map each against the oracle."""
@@ -675,3 +774,45 @@ def test_spectrum_export_needs_the_window_transform(fc):
         with pytest.raises(fc.FFTConvError) as ei:
             p.export_spectrum()
         assert ei.value.status == -5
+
+
+def test_verbose_option_prints_the_reference_debug_lines(fc):
+    """plan option "verbose": the reference's compile-time `debug` prints (src/cudaConvolutionFFT.cu:9,60,68,87,100,114,
+    240,258) at run time, to stderr; silent by default"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import util; fc = util.load_package()\n"
+        "d = np.random.default_rng(0).random((64, 8, 5), dtype=np.float32)\n"
+        "ks = [np.random.default_rng(1).random((10, 4, 5), dtype=np.float32) for _ in range(3)]\n"
+        "with fc.Plan(64, 8, 5, 10, 4) as p:\n"
+        "    p.set_image(d); p.convolve(ks)\n"
+        "    sys.stderr.write('--- verbose on\\n'); sys.stderr.flush()\n"
+        "    p.set_option('verbose', 1); assert p.get_option('verbose') == 1\n"
+        "    p.set_image(d); p.convolve(ks)\n"
+    ) % (util.ROOT + "/tests",)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    quiet, loud = r.stderr.split("--- verbose on\n")
+    assert "fftconv:" not in quiet
+    for want in ("Using GPU : 0", "Data size: h=64, w=8, f=5", "FFT size: h=80, w=16", "Kernel size: h=10, w=4", "N Kernel: 3", "FFT done"):
+        assert want in loud, (want, loud)
+
+
+def test_host_output_copy_threads_start_and_stop_300_times(fc, oracle):
+    """The incident of round 2 (a one-shot call on 92-KB maps died in hipStreamCreateWithFlags, called by freshly
+    started copy threads, about once in 50 starts on some boxes): 300 plans, each starting 1-4 copy threads for
+    small host maps (host_min_kb = 0 forces the threaded path the default spares maps under 1 MiB), every map checked"""
+    H, W, F, kh, kw, n = 140, 150, 1, 13, 11, 6          # 152 x 160 maps = 97 KB
+    data, ks = util.synth(91, H, W, F, kh, kw, n)
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    for i in range(300):
+        with fc.Plan(H, W, F, kh, kw) as p:
+            p.set_option("host_min_kb", 0)
+            p.set_option("host_stream", 1 if i % 5 else 2)
+            p.set_option("host_threads", 1 + i % 4)
+            p.set_option("batch_maps", 2)
+            p.set_image(data)
+            got = p.convolve(ks)
+        for g, r in zip(got, ref):
+            assert util.rel_err(g, r) < TIGHT, i
