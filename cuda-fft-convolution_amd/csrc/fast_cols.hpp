@@ -16,32 +16,7 @@
 #include "butterflies.hpp"
 #include "fast_rows.hpp"  // power_chain, c32x2
 #include "fc_common.hpp"
-
-#ifndef FC_COLS_DBG
-#define FC_COLS_DBG 0   // timing experiments only (wrong results): 1 skip pair pass, 2 no barriers between stages, 4 no gather loads, 8 no stores, 16 contiguous gather addresses (tiled mode)
-#endif
-
-#ifndef FC_COLS_TIMELINE
-#define FC_COLS_TIMELINE 0     // 1: workgroup 0 stamps the 100 MHz wall clock at every phase boundary (tools/cols_timeline.py)
-#endif
-#if FC_COLS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
-#ifndef FC_COLS_TIMELINE_BASE
-#define FC_COLS_TIMELINE_BASE 0   // first tile (of workgroup FC_COLS_TIMELINE_WG) that is stamped; 16 tiles are
-#endif
-#ifndef FC_COLS_TIMELINE_WG
-#define FC_COLS_TIMELINE_WG 0
-#endif
-#define FC_COLS_STAMP(slot) do { if (wg == FC_COLS_TIMELINE_WG && threadIdx.x == 0 && g.timeline && it >= FC_COLS_TIMELINE_BASE && it < FC_COLS_TIMELINE_BASE + 16) g.timeline[(it - FC_COLS_TIMELINE_BASE) * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define FC_COLS_STAMP(slot) ((void)0)
-#endif
-#ifndef FC_COLS_SPLIT_GATHER
-#define FC_COLS_SPLIT_GATHER 2   // next tile's gather issued in: 0 one go at the start of the tile (A/B), 1 halves (start, after
-                                 // stage 3), 2 thirds (start, after stage 3, between the two rounds of stage 2): 28.3 / 27.4 / 27.2 us
-#endif
-#ifndef FC_COLS_NO_PREWAIT
-#define FC_COLS_NO_PREWAIT 0   // 1: A/B, without the vmcnt(0) ahead of the store burst
-#endif
+#include "fc_instrument.hpp"
 
 namespace fc {
 

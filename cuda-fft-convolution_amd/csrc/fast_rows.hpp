@@ -21,13 +21,7 @@
 #pragma once
 #include "butterflies.hpp"
 #include "fc_common.hpp"
-
-#ifndef FC_NT_SLOADS
-#define FC_NT_SLOADS 0   // 1: streaming loads for the image-spectrum rows (A/B)
-#endif
-#ifndef FC_ROWS1_DBG
-#define FC_ROWS1_DBG 0   // timing experiments only (wrong results): 1 no stores, 2 no S loads, 4 no final phase
-#endif
+#include "fc_instrument.hpp"
 
 namespace fc {
 

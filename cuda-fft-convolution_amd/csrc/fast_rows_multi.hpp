@@ -21,29 +21,6 @@
 #pragma once
 #include "fast_rows.hpp"
 
-#ifndef FC_ROWS_NO_FOLD
-#define FC_ROWS_NO_FOLD 0      // 1: A/B, forward stage 1 as a phase of its own for every map
-#endif
-#ifndef FC_ROWSM_DBG
-#define FC_ROWSM_DBG 0         // timing experiments only (wrong results): 1 = P5 without its LDS reads and inverse stage-1 arithmetic (stores + fold only); 2 = no stores of the intermediate
-#endif
-#if (FC_ROWSM_DBG & 2)
-#define FC_ROWSM_STORE(ptr, val) do { const ::fc::c32 fc_w_ = (val); if (fc_w_.x == 1.2345e-30f) *(ptr) = fc_w_; } while (0)
-#else
-#define FC_ROWSM_STORE(ptr, val) FC_STREAM_STORE(ptr, val)
-#endif
-#ifndef FC_ROWS_TIMELINE
-#define FC_ROWS_TIMELINE 0     // 1: one workgroup stamps the 100 MHz wall clock at every phase boundary (tools/rows_timeline.py)
-#endif
-#ifndef FC_ROWS_TIMELINE_WG
-#define FC_ROWS_TIMELINE_WG 1000
-#endif
-#if FC_ROWS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
-#define FC_ROWS_STAMP(slot) do { if (group == FC_ROWS_TIMELINE_WG && kernel0 == 0 && threadIdx.x == 0 && g.timeline && m < 16) g.timeline[m * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define FC_ROWS_STAMP(slot) ((void)0)
-#endif
-
 namespace fc {
 
 template <class C, bool MULTIF = false>

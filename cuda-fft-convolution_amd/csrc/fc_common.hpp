@@ -8,6 +8,8 @@
 #pragma once
 #include <cstdint>
 
+#include "fc_instrument.hpp"
+
 #if defined(__HIPCC__)
 #define FC_HD __host__ __device__ __forceinline__
 #define FC_D __device__ __forceinline__
@@ -34,10 +36,7 @@
 #endif
 
 // Streaming store of one complex value: the intermediate and the maps are written once and not
-// re-read by this kernel (FC_NT_STORES=0 restores plain stores for A/B runs).
-#ifndef FC_NT_STORES
-#define FC_NT_STORES 1
-#endif
+// re-read by this kernel (fc_instrument.hpp: FC_NT_STORES = 0 restores plain stores in diagnostic builds).
 #if defined(__HIP_DEVICE_COMPILE__) && FC_NT_STORES
 #define FC_STREAM_STORE(ptr, val)                                                          \
     do {                                                                                   \
@@ -55,9 +54,6 @@
 // whose other halves are gathered by a neighbouring CU of the same XCD, and a plain load keeps
 // the line in that XCD's L2 for it (27.4 vs 28.5 us per map, FETCH_SIZE back to the algorithmic
 // bytes once the gather is issued in two halves).
-#ifndef FC_NT_LOADS
-#define FC_NT_LOADS 0
-#endif
 #if defined(__HIP_DEVICE_COMPILE__) && FC_NT_LOADS
 #define FC_STREAM_LOAD16(dst, ptr)                                                         \
     do {                                                                                   \

@@ -24,12 +24,7 @@
 
 using namespace fc;
 
-#ifndef FC_HOST_MIN_KB
-#define FC_HOST_MIN_KB 1024    // (diagnostic builds set 0 to reproduce the small-map incident)
-#endif
-#ifndef FC_HOST_BOUNCE
-#define FC_HOST_BOUNCE 1       // 0: diagnostic builds, whole destinations by direct DMA as before
-#endif
+constexpr long FC_HOST_MIN_KB = 1024;   // default of plan option "host_min_kb" (0 reproduces the threaded path for small maps: tests)
 
 namespace {
 
@@ -173,11 +168,9 @@ struct HostRing {
     std::vector<hipStream_t> own_streams;
     char* bounce_base = nullptr;       // two pinned pages per copy thread (unaligned ends of a destination)
     hipError_t prepare_workers(int nthreads) {
-        if (FC_HOST_BOUNCE) {
-            if (hipHostMalloc(reinterpret_cast<void**>(&bounce_base), (size_t)8192 * nthreads, hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                bounce_base = nullptr;
-            }
+        if (hipHostMalloc(reinterpret_cast<void**>(&bounce_base), (size_t)8192 * nthreads, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            bounce_base = nullptr;
         }
         for (int i = 0; i < nthreads; i++) {
             hipStream_t st = nullptr;

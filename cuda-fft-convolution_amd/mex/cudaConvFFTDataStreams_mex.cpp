@@ -50,28 +50,24 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const mxGPUArray* fd = mxGPUCreateFromMxArray(prhs[0]);
     const mwSize* fdim = mxGPUGetDimensions(fd);
     const mwSize fnd = mxGPUGetNumberOfDimensions(fd);
-    const bool good = mxGPUGetClassID(fd) == mxSINGLE_CLASS && mxGPUGetComplexity(fd) == mxCOMPLEX && fnd >= 2 && fnd <= 3 && fdim[0] >= 2;
+    bool good = mxGPUGetClassID(fd) == mxSINGLE_CLASS && mxGPUGetComplexity(fd) == mxCOMPLEX && fnd >= 2 && fnd <= 3 && fdim[0] >= 2;
     const int FFT_H = good ? ((int)fdim[0] - 1) * 2 : 0, FFT_W = good ? (int)fdim[1] : 0, F = good ? (fnd == 3 ? (int)fdim[2] : 1) : 0;   // :176-187
+    // cudaFFTData returns ceil16-sized spectra only; a plan's window is the ceil16 of what it is given, so any other
+    // size would make it read past the array
+    if (good && (FFT_H % 16 != 0 || FFT_W % 16 != 0)) good = false;
     fftconv_multi* m = nullptr;
-    int rc = FFTCONV_ERR_INVALID_ARG;
-    if (good) {
-        fftconv_plan_options opts = {};
-        opts.struct_size = sizeof(opts);
-        opts.exact_window = 1;      // data size == window, kernel size 1: window and transform are FFT_H x FFT_W
-        rc = fftconv_multi_create(&m, FFT_H, FFT_W, F, 1, 1, devs.data(), (int)devs.size(), &opts);
-        if (rc == FFTCONV_OK) rc = fftconv_multi_import_spectrum(m, static_cast<const float*>(mxGPUGetDataReadOnly(fd)), FFTCONV_DEVICE);
-    }
-    mxGPUDestroyGPUArray(fd);
     auto fail = [&](const char* msg) {
+        if (fd) mxGPUDestroyGPUArray(fd);
         if (m) fftconv_multi_destroy(m);
         mexErrMsgIdAndTxt(errId, "%s", msg);
     };
     if (!good) fail("The data must be FFT-ed real array in GPU");
-    if (rc != FFTCONV_OK) fail(fftconv_last_error());
 
+    // the kernel cell before the plans: its largest kernel decides which row kernel they may use
     const int n = (int)mxGetNumberOfElements(prhs[1]);
     std::vector<const float*> kp(n);
     std::vector<int> kh(n), kw(n);
+    int max_kh = 1, max_kw = 1;
     for (int k = 0; k < n; k++) {
         const mxArray* c = mxGetCell(prhs[1], k);
         const mwSize knd = (c && !mxIsGPUArray(c)) ? mxGetNumberOfDimensions(c) : 0;
@@ -81,7 +77,28 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         const mwSize* kd = mxGetDimensions(c);
         kp[k] = static_cast<const float*>(mxGetData(c));
         kh[k] = (int)kd[0]; kw[k] = (int)kd[1];
+        if (kh[k] > max_kh) max_kh = kh[k];
+        if (kw[k] > max_kw) max_kw = kw[k];
     }
+    if (max_kh > FFT_H || max_kw > FFT_W)                                                    // :242-243 of the one-shot source
+        fail("Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+    fftconv_plan_options opts = {};
+    opts.struct_size = sizeof(opts);
+    opts.exact_window = 1;      // data size + largest kernel - 1 == window: window and transform are FFT_H x FFT_W
+    int rc = fftconv_multi_create(&m, FFT_H - max_kh + 1, FFT_W - max_kw + 1, F, max_kh, max_kw, devs.data(), (int)devs.size(), &opts);
+    if (rc == FFTCONV_OK) {
+        fftconv_plan* p0 = nullptr;
+        fftconv_plan_info pi;
+        rc = fftconv_multi_plan(m, 0, &p0, nullptr);
+        if (rc == FFTCONV_OK) rc = fftconv_plan_get_info(p0, &pi);
+        if (rc == FFTCONV_OK && (pi.fft_h != FFT_H || pi.fft_w != FFT_W || pi.spectrum_rows != (int)fdim[0]))
+            fail("The data must be FFT-ed real array in GPU");    // the spectrum the plans would read is not the array given
+    }
+    if (rc == FFTCONV_OK) rc = fftconv_multi_import_spectrum(m, static_cast<const float*>(mxGPUGetDataReadOnly(fd)), FFTCONV_DEVICE);
+    mxGPUDestroyGPUArray(fd);
+    fd = nullptr;
+    if (rc != FFTCONV_OK) fail(fftconv_last_error());
+
     plhs[0] = mxCreateCellMatrix(1, n);
     std::vector<float*> out(n);
     const mwSize cdims[2] = {(mwSize)FFT_H, (mwSize)FFT_W};

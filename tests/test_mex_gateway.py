@@ -334,3 +334,43 @@ def test_multi_gpu_streams_gateway(mex, oracle):
     assert raised and "out of range" in msg
     assert mex.rt.mock_live_gpu_views() == 0
     mex.rt.mock_free(fft_data)
+
+
+@pytest.mark.gpu
+def test_imported_spectra_of_foreign_sizes_and_wide_kernels(mex, oracle):
+    """(advisor, round 2) A complex gpuArray whose sizes are not what cudaFFTData returns (ceil16 windows) must be
+    refused -- a plan's window is the ceil16 of the sizes it is given, so it would read past the array -- and a
+    kernel wider than the specialised row kernel accepts (72 of the 288-point row) must still convolve through an
+    imported spectrum: the gateway sizes the plan by the cell's largest kernel (generic row kernel then)."""
+    torch = pytest.importorskip("torch")
+    # (FFT_H/2+1) x FFT_W with FFT_W = 280 (not a multiple of 16), then FFT_H = 2*(137-1) = 272 is fine but 2*(138-1) = 274 is not
+    for dims in ((137, 280, 1), (138, 288, 1)):
+        z = torch.zeros(dims + (2,), dtype=torch.float32, device="cuda")      # interleaved complex single, all zeros
+        cdims = (ctypes.c_uint64 * len(dims))(*dims)
+        arr = mex.rt.mock_new_gpu_ex(SINGLE, len(dims), cdims, ctypes.c_void_p(z.data_ptr()), 1)
+        for gw in ("cudaConvFFTData", "cudaConvFFTDataStreams"):
+            raised, (eid, msg) = mex.call(gw, [arr, mex.cell([mex.numeric(np.ones((3, 3, 1), np.float32))])])
+            assert raised and eid == ERR_ID and msg == "The data must be FFT-ed real array in GPU", (gw, dims)
+        assert mex.rt.mock_live_gpu_views() == 0
+    # cfg1's window (288 x 288) with kernels up to 100 wide: wider than the 288 = 4.6.12 row kernel's 72
+    H = W = 256
+    kh = kw = 31
+    rng = np.random.default_rng(77)
+    data = rng.random((H, W, 1), dtype=np.float32)
+    raised, out = mex.call("cudaFFTData", [mex.numeric(data), mex.scalar(kh), mex.scalar(kw)])
+    assert not raised, out
+    fft_data = out[0]
+    ks = [rng.random((31, 100, 1), dtype=np.float32), rng.random((90, 12, 1), dtype=np.float32), rng.random((5, 5, 1), dtype=np.float32)]
+    # circular convolution modulo the 288 x 288 window (what the reference computes from a spectrum): the oracle with
+    # MAX_KERNEL = 31 gives the same window and wraps the same way
+    ref = [oracle.conv_direct(data, kh, kw, k) for k in ks]
+    for gw in ("cudaConvFFTData", "cudaConvFFTDataStreams"):
+        raised, out = mex.call(gw, [fft_data, mex.cell([mex.numeric(k) for k in ks])])
+        assert not raised, out
+        for g, r in zip(mex.cell_to_list(out[0], len(ks)), ref):
+            assert g.shape == (288, 288) and util.rel_err(g, r) < 1e-5
+        assert mex.rt.mock_live_gpu_views() == 0
+    # a kernel larger than the window is the reference's size error, not a crash
+    raised, (eid, msg) = mex.call("cudaConvFFTData", [fft_data, mex.cell([mex.numeric(np.ones((300, 3, 1), np.float32))])])
+    assert raised and eid == ERR_ID and "kernel size should be smaller than data size" in msg
+    mex.rt.mock_free(fft_data)

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/cuda-fft-convolution_amd/csrc
 OBJ=/tmp/fc_variant_$NAME
 mkdir -p $OBJ $ROOT/cuda-fft-convolution_amd/ab
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function $*"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function -DFC_INSTRUMENT $*"
 pids=""
 for f in kernels kernels_rows kernels_rows_multi kernels_cols kernels_cols_fwd; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o & pids="$pids $!"
@@ -15,5 +15,5 @@ done
 /opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_api.cpp -o $OBJ/fftconv_api.o & pids="$pids $!"
 /opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_multi.cpp -o $OBJ/fftconv_multi.o & pids="$pids $!"
 for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/cuda-fft-convolution_amd/ab/$NAME.so $OBJ/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/cuda-fft-convolution_amd/ab/$NAME.so $OBJ/*.o -ldl
 echo built cuda-fft-convolution_amd/ab/$NAME.so

@@ -10,6 +10,7 @@
 //   both      1 C + 1 R per CU               C only / R only: the same launch with the other role exiting at once
 //   all C / all R: both workgroups of every CU in one role
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I../../cuda-fft-convolution_amd/csrc fused_roles.hip -o fused_roles
+// (ablations: add -DFC_INSTRUMENT -DFC_ROWSM_DBG=2 -DFC_COLS_DBG=12 for the compute-only variant "fused_roles_nomem")
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
