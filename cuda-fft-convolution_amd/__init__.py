@@ -52,10 +52,10 @@ class PlanInfo(ctypes.Structure):
 class PlanOptions(ctypes.Structure):
     """fftconv_plan_options (include/fftconv.h): choices fixed at plan creation."""
     _fields_ = [("struct_size", ctypes.c_size_t), ("kernel_path", ctypes.c_int), ("rows_group", ctypes.c_int),
-                ("max_transform", ctypes.c_int), ("exact_window", ctypes.c_int)]
+                ("max_transform", ctypes.c_int), ("exact_window", ctypes.c_int), ("blockwise", ctypes.c_int)]
 
-    def __init__(self, kernel_path=0, rows_group=0, max_transform=0, exact_window=0):
-        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform), int(exact_window))
+    def __init__(self, kernel_path=0, rows_group=0, max_transform=0, exact_window=0, blockwise=0):
+        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform), int(exact_window), int(blockwise))
 
 
 def _options_ptr(options):

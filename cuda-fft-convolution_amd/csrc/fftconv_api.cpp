@@ -62,9 +62,15 @@ namespace {
 std::mutex g_live_mutex;
 std::set<const fftconv_plan*> g_live_plans;
 
+// smallest fftconv_plan_options this library accepts: the struct as it was before `blockwise` was appended
+constexpr size_t kOptionsMinSize = offsetof(fftconv_plan_options, exact_window) + sizeof(int);
+bool options_no_blockwise(const fftconv_plan_options* o) {
+    return o && o->struct_size >= offsetof(fftconv_plan_options, blockwise) + sizeof(int) && o->blockwise == 1;
+}
+
 PlanTuning tuning_from(const fftconv_plan_options* o) {
     PlanTuning t;
-    if (!o || o->struct_size < sizeof(fftconv_plan_options)) return t;
+    if (!o || o->struct_size < kOptionsMinSize) return t;
     t.path_mode = o->kernel_path == 1 ? 0 : o->kernel_path == 2 ? 1 : 2;
     t.rows_group = o->rows_group <= 0 ? -1 : o->rows_group;
     t.max_transform = o->max_transform > 0 ? o->max_transform : 0;
@@ -307,7 +313,10 @@ int rows_threads(const Geometry& g) {
 
 }  // namespace
 
+struct TiledState;
+
 struct fftconv_plan {
+    TiledState* tiled = nullptr;   // block-wise (overlap-add) plan: sizes beyond one LDS-resident pass (see TiledState)
     Geometry g;
     Tables t;
     DeviceTables d;
@@ -842,80 +851,160 @@ int check_thread_size(const double* thread_size, int n_thread_size) {
 }
 
 
-// One-shot entry for images whose padded size does not fit a single-pass plan: overlap-add.  The
-// image is cut into blocks of Bh x Bw samples, every block is convolved by an ordinary plan
-// (block + MAX_KERNEL - 1 <= 4224, the fastest specialised length), and the block results are
-// summed on the device into the full FFT_H x FFT_W maps at their offsets (convolution is linear
-// and the blocks partition the image).  The block spectra are computed once and kept; kernels are
-// processed in chunks that fit a few GiB of device maps.
-int tiled_convolution_fft(const float* data, int H, int W, int F, int mkh, int mkw, int n, const float* const* kernels, const int* kh,
-                          const int* kw, int kernel_location, int gpu_id, float* const* out, const fftconv_plan_options* options) {
+// Block-wise plans: sizes whose padded window does not fit a single LDS-resident pass (about 20 000 samples along
+// w), or any size when fftconv_plan_options.max_transform forces it.  Overlap-add: the image is cut into blocks of
+// Bh x Bw samples, every block is convolved by an ordinary plan (block + MAX_KERNEL - 1 <= 4224, the fastest
+// specialised length), and the block results are summed on the device into the full FFT_H x FFT_W maps at their
+// offsets (convolution is linear and the blocks partition the image).  The block spectra are computed once per
+// image and kept (the plan's "spectrum" is their concatenation, so the multi-device copy / broadcast works
+// unchanged); kernels are processed in chunks that fit a few GiB of device maps.  The reference has no such limit
+// (cuFFT plans any size: src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98); kernels larger than MAX_KERNEL
+// cannot be folded block-wise and are rejected.
+}  // namespace
+
+struct TiledState {
+    fftconv_plan* sub = nullptr;     // the block plan (an ordinary plan on the same stream)
+    int H = 0, W = 0, F = 0, mkh = 0, mkw = 0;
+    int Bh = 0, Bw = 0, nbh = 0, nbw = 0, nblk = 0, FH = 0, FW = 0;
+    size_t spec_elems = 0;           // c32 per block spectrum
+    DevBuf<c32> specs;               // block spectra, [block][spec_elems] (own buffer)
+    c32* specs_x = nullptr;          // caller-owned instead (fftconv_plan_use_spectrum_buffer)
+    DevBuf<float> big, tmp, blk;     // full maps of a kernel chunk, block maps of that chunk, one zero-padded image block
+    std::vector<float> hblk;         // host staging of one image block
+    bool have_image = false;
+    c32* spec_base() const { return specs_x ? specs_x : specs.p; }
+    size_t spec_total() const { return spec_elems * (size_t)nblk; }
+    size_t big_map() const { return (size_t)FH * FW; }
+    void release() {
+        if (sub) fftconv_plan_destroy(sub);
+        sub = nullptr;
+        specs.release(); big.release(); tmp.release(); blk.release();
+    }
+};
+
+namespace {
+
+int tiled_unsupported(const char* what) {
+    return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "%s is not available on a block-wise plan (the padded size does not fit one transform pass)", what);
+}
+
+// creates the block plan of a tiled plan; FFTCONV_ERR_UNSUPPORTED_SIZE if no block shape works
+int tiled_create(fftconv_plan* p, int H, int W, int F, int mkh, int mkw, void* hip_stream, const fftconv_plan_options* options) {
     int limit = 4224;
-    if (options && options->struct_size >= sizeof(fftconv_plan_options) && options->max_transform > 0) limit = std::min(limit, options->max_transform);
-    for (int k = 0; k < n; k++)
-        if (kh[k] > mkh || kw[k] > mkw)
-            return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel %dx%d exceeds MAX_KERNEL %dx%d (block-wise path)", kh[k], kw[k], mkh, mkw);
+    if (options && options->struct_size >= kOptionsMinSize && options->max_transform > 0) limit = std::min(limit, options->max_transform);
     const int full_h = limit - mkh + 1, full_w = limit - mkw + 1;
     if (full_h < 1 || full_w < 1)
         return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "kernels up to %dx%d are too large for the block-wise path", mkh, mkw);
+    TiledState* ts = new (std::nothrow) TiledState();
+    if (!ts) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
+    fftconv_plan_options sub_opts = {};
+    if (options && options->struct_size >= kOptionsMinSize) memcpy(&sub_opts, options, std::min(sizeof(sub_opts), options->struct_size));
+    sub_opts.struct_size = sizeof(sub_opts);
+    sub_opts.blockwise = 1;          // the block plan itself is a single pass
     // fewest blocks first: tile only the dimension(s) that need it
     const int cand[3][2] = {{H, std::min(W, full_w)}, {std::min(H, full_h), W}, {std::min(H, full_h), std::min(W, full_w)}};
-    fftconv_plan* sub = nullptr;
-    int Bh = 0, Bw = 0, rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
-    for (int c = 0; c < 3 && !sub; c++) {
-        Bh = cand[c][0]; Bw = cand[c][1];
-        rc = fftconv_plan_create_ex(&sub, Bh, Bw, F, mkh, mkw, gpu_id, nullptr, options);
-        if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) return rc;
+    int rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
+    for (int c = 0; c < 3 && !ts->sub; c++) {
+        ts->Bh = cand[c][0]; ts->Bw = cand[c][1];
+        rc = fftconv_plan_create_ex(&ts->sub, ts->Bh, ts->Bw, F, mkh, mkw, p->gpu_id, hip_stream, &sub_opts);
+        if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) { delete ts; return rc; }
     }
-    if (!sub) return rc;
-    const int nbh = (H + Bh - 1) / Bh, nbw = (W + Bw - 1) / Bw, nblk = nbh * nbw;
-    const int FH = fft_size16(H + mkh - 1), FW = fft_size16(W + mkw - 1);
-    const Geometry& g = sub->g;
-    const size_t big_map = (size_t)FH * FW, blk_map = g.map_elems(), spec_elems = g.spectrum_elems();
+    if (!ts->sub) { delete ts; return rc; }
+    ts->H = H; ts->W = W; ts->F = F; ts->mkh = mkh; ts->mkw = mkw;
+    ts->nbh = (H + ts->Bh - 1) / ts->Bh; ts->nbw = (W + ts->Bw - 1) / ts->Bw; ts->nblk = ts->nbh * ts->nbw;
+    ts->FH = fft_size16(H + mkh - 1); ts->FW = fft_size16(W + mkw - 1);
+    ts->spec_elems = ts->sub->g.spectrum_elems();
+    p->tiled = ts;
+    Geometry& g = p->g;             // what fftconv_plan_get_info reports
+    g = ts->sub->g;
+    g.H = H; g.W = W; g.fft_h = ts->FH; g.fft_w = ts->FW; g.exact_window = false;
+    p->num_cus = ts->sub->num_cus;
+    return 0;
+}
+
+int tiled_set_image(fftconv_plan* p, const float* data, int location) {
+    TiledState* ts = p->tiled;
+    fftconv_plan* sub = ts->sub;
+    ts->have_image = false;
+    if (!ts->specs_x)
+        if (int rc = ts->specs.ensure(ts->spec_total())) return rc;
+    const int H = ts->H, W = ts->W, F = ts->F, Bh = ts->Bh, Bw = ts->Bw;
+    FC_VERBOSE(p, "Data size: h=%d, w=%d, f=%d", H, W, F);
+    FC_VERBOSE(p, "FFT size: h=%d, w=%d (block-wise: %d x %d blocks of %d x %d samples, block transforms %d x %d)", ts->FH, ts->FW, ts->nbh, ts->nbw,
+               Bh, Bw, sub->g.Lh, sub->g.Lw);
+    if (location == FFTCONV_HOST) ts->hblk.assign((size_t)Bh * Bw * F, 0.f);
+    else if (int rc = ts->blk.ensure((size_t)Bh * Bw * F)) return rc;
+    for (int b = 0; b < ts->nblk; b++) {
+        const int y0 = (b % ts->nbh) * Bh, x0 = (b / ts->nbh) * Bw;
+        const int hv = std::min(Bh, H - y0), wv = std::min(Bw, W - x0);
+        if (int rc = fftconv_plan_use_spectrum_buffer(sub, ts->spec_base() + (size_t)b * ts->spec_elems, ts->spec_elems * sizeof(c32))) return rc;
+        if (location == FFTCONV_HOST) {
+            std::fill(ts->hblk.begin(), ts->hblk.end(), 0.f);
+            for (int f = 0; f < F; f++)
+                for (int x = 0; x < wv; x++)
+                    memcpy(&ts->hblk[((size_t)f * Bw + x) * Bh], &data[((size_t)f * W + (x0 + x)) * H + y0], (size_t)hv * sizeof(float));
+            if (int rc = fftconv_plan_set_image(sub, ts->hblk.data(), FFTCONV_HOST)) return rc;   // synchronous for host input
+        } else {
+            // the block, zero-padded, on the device: one strided copy per feature plane (h is contiguous)
+            if (hv < Bh || wv < Bw) HIP_TRY(hipMemsetAsync(ts->blk.p, 0, (size_t)Bh * Bw * F * sizeof(float), sub->stream));
+            for (int f = 0; f < F; f++)
+                HIP_TRY(hipMemcpy2DAsync(ts->blk.p + (size_t)f * Bw * Bh, (size_t)Bh * sizeof(float),
+                                         data + ((size_t)f * W + x0) * H + y0, (size_t)H * sizeof(float), (size_t)hv * sizeof(float), (size_t)wv,
+                                         hipMemcpyDeviceToDevice, sub->stream));
+            if (int rc = fftconv_plan_set_image(sub, ts->blk.p, FFTCONV_DEVICE)) return rc;
+        }
+    }
+    ts->have_image = true;
+    return 0;
+}
+
+// n kernels (pointers, any location) -> n full maps.  out_packed != nullptr: device memory, maps consecutive (the block
+// results are summed straight into it); else one pointer per map in `out` (host or device memory).
+int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const int* kh, const int* kw, int kernel_location,
+                   float* const* out, int out_location, float* out_packed) {
+    TiledState* ts = p->tiled;
+    fftconv_plan* sub = ts->sub;
+    if (!ts->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
+    for (int k = 0; k < n; k++) {
+        if (!kernels[k]) return fail(FFTCONV_ERR_INVALID_ARG, "kernel %d is NULL", k);
+        if (kh[k] < 1 || kw[k] < 1 || kh[k] > ts->FH || kw[k] > ts->FW)      // src/cudaConvolutionFFT.cu:242
+            return fail(FFTCONV_ERR_KERNEL_SHAPE,
+                        "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
+        if (kh[k] > ts->mkh || kw[k] > ts->mkw)
+            return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel %dx%d exceeds MAX_KERNEL %dx%d (block-wise path)", kh[k], kw[k], ts->mkh, ts->mkw);
+    }
+    const size_t big_map = ts->big_map(), blk_map = sub->g.map_elems();
     const size_t budget = (size_t)6 << 30;
     const int nc = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / ((big_map + blk_map) * sizeof(float))));
-    DevBuf<c32> specs;
-    DevBuf<float> big, tmp;
-    std::vector<float> blk((size_t)Bh * Bw * F);
+    if (!out_packed)
+        if (int rc = ts->big.ensure(big_map * nc)) return rc;
+    if (int rc = ts->tmp.ensure(blk_map * nc)) return rc;
     std::vector<float*> tptr(nc);
-    auto finish = [&](int code) {
-        const std::string keep = g_last_error;
-        (void)hipStreamSynchronize(sub->stream);
-        fftconv_plan_destroy(sub);
-        specs.release(); big.release(); tmp.release();
-        g_last_error = keep;
-        return code;
-    };
-    if ((rc = specs.ensure(spec_elems * nblk)) || (rc = big.ensure(big_map * nc)) || (rc = tmp.ensure(blk_map * nc))) return finish(rc);
-    for (int j = 0; j < nc; j++) tptr[j] = tmp.p + (size_t)j * blk_map;
-    // block spectra, once
-    for (int b = 0; b < nblk; b++) {
-        const int y0 = (b % nbh) * Bh, x0 = (b / nbh) * Bw;
-        const int hv = std::min(Bh, H - y0), wv = std::min(Bw, W - x0);
-        std::fill(blk.begin(), blk.end(), 0.f);
-        for (int f = 0; f < F; f++)
-            for (int x = 0; x < wv; x++)
-                memcpy(&blk[((size_t)f * Bw + x) * Bh], &data[((size_t)f * W + (x0 + x)) * H + y0], (size_t)hv * sizeof(float));
-        if ((rc = fftconv_plan_use_spectrum_buffer(sub, specs.p + (size_t)b * spec_elems, spec_elems * sizeof(c32)))) return finish(rc);
-        if ((rc = fftconv_plan_set_image(sub, blk.data(), FFTCONV_HOST))) return finish(rc);   // synchronous for host input
-    }
+    for (int j = 0; j < nc; j++) tptr[j] = ts->tmp.p + (size_t)j * blk_map;
+    FC_VERBOSE(p, "N Kernel: %d (block-wise: %d blocks, %d kernels per chunk)", n, ts->nblk, nc);
     for (int k0 = 0; k0 < n; k0 += nc) {
         const int nk = std::min(nc, n - k0);
-        if (hipMemsetAsync(big.p, 0, big_map * nk * sizeof(float), sub->stream) != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "hipMemsetAsync failed"));
-        for (int b = 0; b < nblk; b++) {
-            const int y0 = (b % nbh) * Bh, x0 = (b / nbh) * Bw;
-            if ((rc = fftconv_plan_use_spectrum_buffer(sub, specs.p + (size_t)b * spec_elems, spec_elems * sizeof(c32)))) return finish(rc);
-            if ((rc = fftconv_plan_mark_spectrum_valid(sub))) return finish(rc);
-            if ((rc = fftconv_plan_convolve(sub, nk, kernels + k0, kh + k0, kw + k0, kernel_location, tptr.data(), FFTCONV_DEVICE))) return finish(rc);
-            hipError_t e = launch_add_window(big.p, FH, FW, big_map, y0, x0, tmp.p, g.fft_h, g.fft_w, blk_map, nk, sub->stream);
-            if (e != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "overlap-add failed: %s", hipGetErrorString(e)));
+        float* big = out_packed ? out_packed + (size_t)k0 * big_map : ts->big.p;
+        HIP_TRY(hipMemsetAsync(big, 0, big_map * nk * sizeof(float), sub->stream));
+        for (int b = 0; b < ts->nblk; b++) {
+            const int y0 = (b % ts->nbh) * ts->Bh, x0 = (b / ts->nbh) * ts->Bw;
+            if (int rc = fftconv_plan_use_spectrum_buffer(sub, ts->spec_base() + (size_t)b * ts->spec_elems, ts->spec_elems * sizeof(c32))) return rc;
+            if (int rc = fftconv_plan_mark_spectrum_valid(sub)) return rc;
+            if (int rc = fftconv_plan_convolve(sub, nk, kernels + k0, kh + k0, kw + k0, kernel_location, tptr.data(), FFTCONV_DEVICE)) return rc;
+            hipError_t e = launch_add_window(big, ts->FH, ts->FW, big_map, y0, x0, ts->tmp.p, sub->g.fft_h, sub->g.fft_w, blk_map, nk, sub->stream);
+            if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "overlap-add failed: %s", hipGetErrorString(e));
         }
-        if (hipStreamSynchronize(sub->stream) != hipSuccess) return finish(fail(FFTCONV_ERR_HIP, "stream synchronisation failed"));
-        for (int j = 0; j < nk; j++)
-            if (hipMemcpy(out[k0 + j], big.p + (size_t)j * big_map, big_map * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-                return finish(fail(FFTCONV_ERR_HIP, "device-to-host copy failed"));
+        if (!out_packed) {
+            for (int j = 0; j < nk; j++) {
+                if (!out[k0 + j]) return fail(FFTCONV_ERR_INVALID_ARG, "output %d is NULL", k0 + j);
+                HIP_TRY(hipMemcpyAsync(out[k0 + j], big + (size_t)j * big_map, big_map * sizeof(float),
+                                       out_location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sub->stream));
+            }
+            if (out_location == FFTCONV_HOST || k0 + nc < n) HIP_TRY(hipStreamSynchronize(sub->stream));   // `big` is reused by the next chunk
+        }
     }
-    return finish(0);
+    FC_VERBOSE(p, "FFT done");
+    return 0;
 }
 
 }  // namespace
@@ -959,19 +1048,26 @@ int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feat
     if (gpu_id >= ndev) return fail(FFTCONV_ERR_NO_DEVICE, "gpu_id %d out of range (%d devices)", gpu_id, ndev);
     fftconv_plan* p = new (std::nothrow) fftconv_plan();
     if (!p) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
-    if (options && options->struct_size < sizeof(fftconv_plan_options)) {
+    if (options && options->struct_size < kOptionsMinSize) {
         delete p;
         return fail(FFTCONV_ERR_INVALID_ARG, "fftconv_plan_options.struct_size is not set");
     }
     const PlanTuning tune = tuning_from(options);
-    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, tune)) {
-        delete p;
-        return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
-                    "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform%s", data_h, data_w,
-                    feature_dim, max_kernel_h, max_kernel_w, tune.max_transform > 0 ? " within max_transform" : "");
-    }
     p->gpu_id = gpu_id;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, tune)) {
+        // too large for one LDS-resident pass (or beyond max_transform): a block-wise plan, unless the caller opted out
+        int rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
+        if (options_no_blockwise(options) || tune.exact_window)
+            (void)fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform%s", data_h,
+                       data_w, feature_dim, max_kernel_h, max_kernel_w, tune.max_transform > 0 ? " within max_transform" : "");
+        else
+            rc = tiled_create(p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, hip_stream, options);
+        if (rc) { delete p; return rc; }
+        { std::lock_guard<std::mutex> lk(g_live_mutex); g_live_plans.insert(p); }
+        *plan = p;
+        return 0;
+    }
     int rc = 0;
     do {
         if ((rc = use_device(p))) break;
@@ -1044,6 +1140,11 @@ int fftconv_plan_destroy(fftconv_plan* plan) {
     }
     (void)hipSetDevice(plan->gpu_id);
     (void)hipStreamSynchronize(plan->stream);
+    if (plan->tiled) {
+        plan->tiled->release();
+        delete plan->tiled;
+        plan->tiled = nullptr;
+    }
     plan->release_all();
     delete plan;
     return 0;
@@ -1065,6 +1166,14 @@ int fftconv_plan_get_info(const fftconv_plan* plan, fftconv_plan_info* info) {
     info->out_w = plan->opt_region ? plan->out_w : g.fft_w;
     info->out_map_bytes = plan->out_elems() * sizeof(float);
     info->workspace_bytes = plan->A.bytes() + plan->Y.bytes() + plan->K.bytes() + plan->O.bytes() + plan->I.bytes();
+    if (const TiledState* ts = plan->tiled) {     // block-wise: the window of the whole image; the spectrum is every block's
+        info->spectrum_bytes = ts->spec_total() * sizeof(c32);
+        info->map_bytes = info->out_map_bytes = ts->big_map() * sizeof(float);
+        info->out_h = ts->FH; info->out_w = ts->FW;
+        fftconv_plan_info si;
+        if (fftconv_plan_get_info(ts->sub, &si) == 0)
+            info->workspace_bytes = si.workspace_bytes + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes() + (ts->specs_x ? 0 : ts->specs.bytes());
+    }
     return 0;
 }
 
@@ -1074,6 +1183,7 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
     fftconv_plan* p = plan;
     const Geometry& g = p->g;
     if (int rc = use_device(p)) return rc;
+    if (p->tiled) return tiled_set_image(p, data, location);
     const float* dimg = data;
     if (location == FFTCONV_HOST) {
         const size_t n = (size_t)g.H * g.W * g.F;
@@ -1114,6 +1224,13 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
 int fftconv_plan_spectrum(fftconv_plan* plan, void** device_ptr, size_t* bytes) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     if (int rc = use_device(plan)) return rc;
+    if (TiledState* ts = plan->tiled) {          // every block's spectrum, one after the other
+        if (!ts->specs_x)
+            if (int rc = ts->specs.ensure(ts->spec_total())) return rc;
+        if (device_ptr) *device_ptr = ts->spec_base();
+        if (bytes) *bytes = ts->spec_total() * sizeof(c32);
+        return 0;
+    }
     if (int rc = plan->ensure_spectrum()) return rc;
     if (device_ptr) *device_ptr = plan->spec();
     if (bytes) *bytes = plan->g.spectrum_elems() * sizeof(c32);
@@ -1123,6 +1240,7 @@ int fftconv_plan_spectrum(fftconv_plan* plan, void** device_ptr, size_t* bytes) 
 static int spectrum_exchange(fftconv_plan* p, float* spectrum, int location, bool to_natural) {
     if (!p || !spectrum) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
     if (location != FFTCONV_HOST && location != FFTCONV_DEVICE) return fail(FFTCONV_ERR_INVALID_ARG, "bad location");
+    if (p->tiled) return tiled_unsupported("the spectrum in the reference's order");
     const Geometry& g = p->g;
     if (!g.exact_window)
         return fail(FFTCONV_ERR_UNSUPPORTED_SIZE,
@@ -1163,10 +1281,15 @@ int fftconv_plan_import_spectrum(fftconv_plan* plan, const float* spectrum, int 
 
 int fftconv_plan_use_spectrum_buffer(fftconv_plan* plan, void* device_ptr, size_t bytes) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    const size_t need = (plan->tiled ? plan->tiled->spec_total() : plan->g.spectrum_elems()) * sizeof(c32);
     if (device_ptr) {
-        if (bytes < plan->g.spectrum_elems() * sizeof(c32) || (reinterpret_cast<uintptr_t>(device_ptr) & 15))
-            return fail(FFTCONV_ERR_INVALID_ARG, "spectrum buffer too small (%zu < %zu bytes) or not 16-byte aligned", bytes,
-                        plan->g.spectrum_elems() * sizeof(c32));
+        if (bytes < need || (reinterpret_cast<uintptr_t>(device_ptr) & 15))
+            return fail(FFTCONV_ERR_INVALID_ARG, "spectrum buffer too small (%zu < %zu bytes) or not 16-byte aligned", bytes, need);
+    }
+    if (plan->tiled) {
+        plan->tiled->specs_x = reinterpret_cast<c32*>(device_ptr);
+        plan->tiled->have_image = false;
+        return 0;
     }
     plan->Sx = reinterpret_cast<c32*>(device_ptr);
     plan->have_image = false;
@@ -1175,6 +1298,11 @@ int fftconv_plan_use_spectrum_buffer(fftconv_plan* plan, void* device_ptr, size_
 
 int fftconv_plan_mark_spectrum_valid(fftconv_plan* plan) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
+    if (plan->tiled) {
+        if (!plan->tiled->spec_base()) return fail(FFTCONV_ERR_NO_IMAGE, "the plan has no spectrum buffer yet (fftconv_plan_spectrum / fftconv_plan_use_spectrum_buffer)");
+        plan->tiled->have_image = true;
+        return 0;
+    }
     if (!plan->spec()) return fail(FFTCONV_ERR_NO_IMAGE, "the plan has no spectrum buffer yet (fftconv_plan_spectrum / fftconv_plan_use_spectrum_buffer)");
     plan->have_image = true;
     return 0;
@@ -1186,6 +1314,13 @@ int fftconv_plan_convolve_packed(fftconv_plan* plan, int n_kernel, const float* 
     if (n_kernel == 0) return 0;
     if (!kernels_device || !out_device) return fail(FFTCONV_ERR_INVALID_ARG, "NULL kernel or output pointer");
     if (int rc = use_device(plan)) return rc;
+    if (plan->tiled) {
+        const size_t per = (size_t)plan->tiled->F * kernel_h * kernel_w;
+        std::vector<const float*> kp(n_kernel);
+        std::vector<int> khs(n_kernel, kernel_h), kws(n_kernel, kernel_w);
+        for (int j = 0; j < n_kernel; j++) kp[j] = kernels_device + per * j;
+        return tiled_convolve(plan, n_kernel, kp.data(), khs.data(), kws.data(), FFTCONV_DEVICE, nullptr, FFTCONV_DEVICE, out_device);
+    }
     Sink sink;
     sink.packed = out_device;
     return run_group(plan, n_kernel, kernels_device, kernel_h, kernel_w, sink);
@@ -1197,6 +1332,7 @@ int fftconv_plan_prepare_kernels_packed(fftconv_plan* plan, int n_kernel, const 
     if (n_kernel == 0) return 0;
     if (!kernels_device) return fail(FFTCONV_ERR_INVALID_ARG, "NULL kernel pointer");
     fftconv_plan* p = plan;
+    if (p->tiled) return 0;        // block-wise: the kernels are transformed per block inside convolve
     if (int rc = use_device(p)) return rc;
     if (int rc = check_kernel_size(p, kernel_h, kernel_w)) return rc;
     const BatchSizes bs = batch_sizes(p, n_kernel, kernel_w);
@@ -1216,6 +1352,15 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
     fftconv_plan* p = plan;
     const Geometry& g = p->g;
     if (int rc = use_device(p)) return rc;
+    if (p->tiled) {
+        if (int rc = tiled_convolve(p, n_kernel, kernels, kernel_h, kernel_w, kernel_location, out, out_location, nullptr)) {
+            const std::string keep = g_last_error;
+            (void)hipStreamSynchronize(p->tiled->sub->stream);   // nothing may still be writing into the caller's buffers
+            g_last_error = keep;
+            return rc;
+        }
+        return 0;
+    }
     if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
     // validate everything up front so nothing is launched on a bad cell (the reference fails
     // mid-loop and leaks: SURVEY D3)
@@ -1253,6 +1398,7 @@ int fftconv_plan_set_stream(fftconv_plan* plan, void* hip_stream) {
     // (prepared column spectra stay: they count again once the plan is back on the stream they were produced on --
     //  the image transform of the multi-GPU step borrows the plan for a side stream and hands it back)
     plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->tiled) return fftconv_plan_set_stream(plan->tiled->sub, hip_stream);
     return 0;
 }
 
@@ -1265,6 +1411,11 @@ int fftconv_plan_synchronize(fftconv_plan* plan) {
 
 int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (plan->tiled) {      // block-wise: options act on the block plan; the window options have no block-wise form
+        if (!strcmp(name, "output_region") && value != 0) return tiled_unsupported("output_region");
+        if (!strcmp(name, "verbose")) plan->opt_verbose = value != 0;
+        return fftconv_plan_set_option(plan->tiled->sub, name, value);
+    }
     if (!strcmp(name, "tune_placement")) { plan->opt_tune_placement = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
@@ -1312,6 +1463,8 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
 
 int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!plan || !name || !value) return fail(FFTCONV_ERR_INVALID_ARG, "null argument");
+    if (!strcmp(name, "blockwise")) { *value = plan->tiled ? plan->tiled->nblk : 0; return 0; }   // read-only: number of blocks (0 = one pass)
+    if (plan->tiled) return fftconv_plan_get_option(plan->tiled->sub, name, value);
     if (!strcmp(name, "batch_maps")) { *value = plan->opt_batch_maps; return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { *value = plan->opt_kernel_chunk_mb; return 0; }
     if (!strcmp(name, "tune_placement")) { *value = plan->opt_tune_placement; return 0; }
@@ -1329,6 +1482,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
 
 int fftconv_plan_get_profile(fftconv_plan* plan, fftconv_profile* prof, int reset) {
     if (!plan || !prof) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    if (plan->tiled) return fftconv_plan_get_profile(plan->tiled->sub, prof, reset);
     if (int rc = use_device(plan)) return rc;
     if (int rc = plan->prof_collect()) return rc;
     for (int i = 0; i < PK_COUNT; i++) {
@@ -1368,13 +1522,8 @@ int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int fe
     if (fft_h) *fft_h = fft_size16(data_h + max_kernel_h - 1);
     if (fft_w) *fft_w = fft_size16(data_w + max_kernel_w - 1);
     fftconv_plan* p = nullptr;
-    if (int rc = fftconv_plan_create_ex(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr, options)) {
-        // too large for one single-pass plan: block-wise (overlap-add) over ordinary plans
-        if (rc == FFTCONV_ERR_UNSUPPORTED_SIZE && n_kernel > 0)
-            return tiled_convolution_fft(data, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, n_kernel, kernels, kernel_h,
-                                         kernel_w, kernel_location, gpu_id, out, options);
-        return rc;
-    }
+    // (sizes beyond one single-pass plan: the plan is block-wise -- overlap-add over ordinary plans -- by itself)
+    if (int rc = fftconv_plan_create_ex(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr, options)) return rc;
     int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);
     if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, kernel_location, out, FFTCONV_HOST);
     std::string keep = g_last_error;

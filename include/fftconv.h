@@ -156,13 +156,21 @@ typedef struct fftconv_plan_options {
                          *    the specialised path); 2: specialised kernels with a row-major intermediate */
     int rows_group;     /* maps one workgroup of the spectral-row kernel walks with its image-spectrum row in
                          *    registers (F = 1): 0 (default) chosen per launch, 1 one map per workgroup, n > 1 fixed */
-    int max_transform;  /* > 0: largest transform length a plan may use; creation fails with
-                         *    FFTCONV_ERR_UNSUPPORTED_SIZE beyond it and the one-shot entry goes block-wise
-                         *    (overlap-add) with blocks of at most this size */
+    int max_transform;  /* > 0: largest transform length a plan may use; beyond it the plan is block-wise
+                         *    (overlap-add) with blocks of at most this size (see `blockwise`) */
     int exact_window;   /* 1: the transform lengths must be the ceil16 window FFT_H x FFT_W itself (the
                          *    reference's circular modulus, plan_info.exact_window = 1) -- what
                          *    fftconv_plan_export_spectrum / _import_spectrum need; creation fails with
                          *    FFTCONV_ERR_UNSUPPORTED_SIZE when the window has a prime factor above 17 */
+    int blockwise;      /* Padded sizes beyond one LDS-resident transform pass (about 20 000 samples along w) or beyond
+                         *    max_transform: 0 (default) the plan convolves block-wise -- overlap-add over an ordinary block
+                         *    plan, block spectra kept per image; every plan entry point works (two-step, packed
+                         *    device-resident, multi-device), except the spectrum exchange in the reference's order and
+                         *    "output_region"; kernels larger than MAX_KERNEL are rejected there.  1: creation fails
+                         *    with FFTCONV_ERR_UNSUPPORTED_SIZE instead.  (Appended in 0.2: a struct_size without this
+                         *    field is accepted and means 0.)  fftconv_plan_get_option "blockwise" reads the number of
+                         *    blocks of a plan (0 = single pass).  The reference plans cuFFT for any size:
+                         *    src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98. */
 } fftconv_plan_options;
 int fftconv_plan_create_ex(fftconv_plan **plan, int data_h, int data_w, int feature_dim,
                            int max_kernel_h, int max_kernel_w, int gpu_id, void *hip_stream,

@@ -623,7 +623,7 @@ def test_blockwise_one_shot_matches_oracle(fc, oracle, shape):
     direct = fc.cudaConvolutionFFT(data, kh, kw, ks)
     small = {"max_transform": 64}
     with pytest.raises(fc.FFTConvError) as ei:
-        fc.Plan(H, W, F, kh, kw, options=small)        # the plan API itself reports the limit
+        fc.Plan(H, W, F, kh, kw, options=dict(small, blockwise=1))   # opted out of block-wise plans: the limit is reported
     assert ei.value.status == -5
     got = fc.cudaConvolutionFFT(data, kh, kw, ks, options=small)
     for g, d, r in zip(got, direct, ref):
@@ -643,11 +643,67 @@ def test_blockwise_one_shot_beyond_the_single_pass_limit(fc, oracle):
     data = rng.random((H, W, 1), dtype=np.float32)
     ks = [rng.random((kh, kw, 1), dtype=np.float32) for _ in range(2)]
     with pytest.raises(fc.FFTConvError) as ei:
-        fc.Plan(H, W, 1, kh, kw)
+        fc.Plan(H, W, 1, kh, kw, options={"blockwise": 1})
     assert ei.value.status == -5
+    ref = oracle.conv_fft(data, kh, kw, ks)
     got = fc.cudaConvolutionFFT(data, kh, kw, ks)
-    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+    for g, r in zip(got, ref):
         assert util.rel_err(g, r) < TIGHT
+    # the same size through the two-step API (cudaFFTData / cudaConvFFTData, src/cudaFFTData.cu:72-103,
+    # src/cudaConvFFTData.cu:92-98: the reference plans cuFFT for any size): the handle is a block-wise plan
+    h = fc.cudaFFTData(data, kh, kw)
+    assert h.get_option("blockwise") > 1 and (h.info.fft_h, h.info.fft_w) == (util.ceil16(H + kh - 1), util.ceil16(W + kw - 1))
+    for rep in range(2):
+        for g, r in zip(fc.cudaConvFFTData(h, ks), ref):
+            assert util.rel_err(g, r) < TIGHT
+    h.destroy()
+
+
+@pytest.mark.parametrize("shape", [
+    (150, 40, 2, 9, 7, 3),      # h tiled only
+    (130, 140, 2, 12, 10, 3),   # both dimensions, ragged edge blocks
+])
+def test_blockwise_plan_api_every_entry(fc, oracle, shape):
+    """Block-wise plans behind the plan API (max_transform = 64 makes small problems take it): host and
+    device-resident images, pointer-array and packed device-resident outputs, a second image through the same plan,
+    the multi-device handle (the spectrum copied between plans is every block's), and what has no block-wise form
+    fails with a message instead of computing something else"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    small = {"max_transform": 64}
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    data2 = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    ref, ref2 = oracle.conv_fft(data, kh, kw, ks), oracle.conv_fft(data2, kh, kw, ks)
+    fh, fw = util.ceil16(H + kh - 1), util.ceil16(W + kw - 1)
+    with fc.Plan(H, W, F, kh, kw, options=small) as p:
+        assert p.get_option("blockwise") > 1 and (p.info.fft_h, p.info.fft_w) == (fh, fw) and p.info.map_bytes == fh * fw * 4
+        p.set_image(data)
+        for g, r in zip(p.convolve(ks), ref):
+            assert g.shape == (fh, fw) and util.rel_err(g, r) < TIGHT
+        # device-resident image, packed device-resident kernels and maps (what bench.py uses)
+        img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(data2, (2, 1, 0)))).to(dev)
+        k_d = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in ks]))).to(dev)
+        out = torch.full((n, fw, fh), float("nan"), dtype=torch.float32, device=dev)
+        p.set_image_device(img_d.data_ptr())
+        p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+        for j, r in enumerate(ref2):
+            assert util.rel_err(out[j].cpu().numpy().T, r) < TIGHT
+        with pytest.raises(fc.FFTConvError) as ei:
+            p.set_option("output_region", 1)
+        assert ei.value.status == -5
+        with pytest.raises(fc.FFTConvError) as ei:          # a kernel beyond MAX_KERNEL cannot be folded block-wise
+            p.convolve([np.zeros((kh + 1, kw, F), np.float32)])
+        assert ei.value.status == -4
+    # several plans from one process: each is block-wise, the spectrum copy moves every block's spectrum
+    with fc.MultiPlan(H, W, F, kh, kw, [0, 0], options=small) as mp:
+        mp.set_image(data)
+        for g, r in zip(mp.convolve(ks), ref):
+            assert util.rel_err(g, r) < TIGHT
 
 
 # ---- output_region: full / same / valid parts of the padded window ---------------------------------

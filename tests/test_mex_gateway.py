@@ -350,7 +350,9 @@ def test_imported_spectra_of_foreign_sizes_and_wide_kernels(mex, oracle):
         arr = mex.rt.mock_new_gpu_ex(SINGLE, len(dims), cdims, ctypes.c_void_p(z.data_ptr()), 1)
         for gw in ("cudaConvFFTData", "cudaConvFFTDataStreams"):
             raised, (eid, msg) = mex.call(gw, [arr, mex.cell([mex.numeric(np.ones((3, 3, 1), np.float32))])])
-            assert raised and eid == ERR_ID and msg == "The data must be FFT-ed real array in GPU", (gw, dims)
+            # (the reference's multi-GPU source raises with the id of MATLAB's GPU example, src/cudaConvFFTDataStreams.cu)
+            assert raised and eid in (ERR_ID, "parallel:gpu:mexGPUExample:InvalidInput"), (gw, dims, eid)
+            assert msg == "The data must be FFT-ed real array in GPU", (gw, dims, msg)
         assert mex.rt.mock_live_gpu_views() == 0
     # cfg1's window (288 x 288) with kernels up to 100 wide: wider than the 288 = 4.6.12 row kernel's 72
     H = W = 256
