@@ -21,8 +21,12 @@ namespace fc {
 //   4224 = 8 x 24 x 22 (cfg3; cfg4's 4160 window also runs on it): butterflies 528 / 176 / 192
 //   2112 = 8 x 12 x 22, 2 rows (cfg5):                            528 / 352 / 192
 //   1152 = 6 x  8 x 24, 4 rows (cfg2's 1088 window):              768 / 576 / 192
-//   8448 = 16 x 24 x 22, 384 threads, two workgroups per CU (8192-sized images): 528 / 352 / 384
-//   6144 = 16 x 24 x 16, 384 threads, two workgroups per CU (images between 4224 and 6144): 384 / 256 / 384
+//   8448 = 16 x 24 x 22, 2 rows per workgroup of 768 threads (8192-sized images): 528 / 352 / 384 per row.  (Round 3: as
+//          one row per 384-thread workgroup only ONE workgroup was ever resident per CU -- at more than 128 VGPRs the
+//          hardware does not admit a second 6-wave workgroup, profiles/r03a_fused_roles_sq_counters.txt: 5.7 waves per CU;
+//          a 12-wave workgroup is resident whole)
+//   6144 = 16 x 24 x 16, 384 threads (images between 4224 and 6144): 384 / 256 / 384; its F = 1 kernels need <= 128 VGPRs
+//          (4 waves per SIMD), where two 6-wave workgroups do share a CU
 //   3072 = 8 x 24 x 16 (images around 2500 - 3000):               384 / 128 / 192
 //   1536 = 8 x 12 x 16, 2 rows (1280-wide images):                384 / 256 / 192
 //    768 = 4 x 12 x 16, 4 rows (640 / 720-sized images):          768 / 256 / 192
@@ -30,9 +34,9 @@ namespace fc {
 //    288 = 4 x  6 x 12, 8 rows (cfg1):                            576 / 384 / 192
 // Listed with ascending NZ2 per length (the dispatcher takes the first that covers the kernel).
 #define FC_FAST_ROW_CONFIGS(X)      \
-    X(8448, 16, 24, 22, 384, 1, 3)  \
-    X(8448, 16, 24, 22, 384, 1, 6)  \
-    X(8448, 16, 24, 22, 384, 1, 24) \
+    X(8448, 16, 24, 22, 768, 2, 3)  \
+    X(8448, 16, 24, 22, 768, 2, 6)  \
+    X(8448, 16, 24, 22, 768, 2, 24) \
     X(6144, 16, 24, 16, 384, 1, 3)  \
     X(6144, 16, 24, 16, 384, 1, 6)  \
     X(6144, 16, 24, 16, 384, 1, 24) \

@@ -872,3 +872,22 @@ def test_host_output_copy_threads_start_and_stop_300_times(fc, oracle):
             got = p.convolve(ks)
         for g, r in zip(got, ref):
             assert util.rel_err(g, r) < TIGHT, i
+
+
+def test_full_size_five_feature_maps_vs_oracle(fc, oracle):
+    """The reference's own demo runs F = 5 feature planes (demoCudaConvolutionFFT.m:37-42; sumAlongFeatures,
+    src/cudaConvFFTData.cuh:70-92).  At cfg3's geometry -- 4096 x 4096 x 5 image, 127 x 127 x 5 kernels, the walk over
+    (map, feature) pairs of the multi-map row kernel -- three maps in full against the oracle, plus the all-ones
+    identity: a map's sum is the sum over features of sum(image_f) * sum(kernel_f)."""
+    H = W = 4096
+    kh = kw = 127
+    F, n = 5, 3
+    img, ks = util.synth(55, H, W, F, kh, kw, n)
+    ks[1] = np.asfortranarray(ks[1][:101, :90, :])          # ragged cell: a group of its own
+    got = fc.cudaConvolutionFFT(img, kh, kw, ks)
+    ref = oracle.conv_fft(img, kh, kw, ks)
+    for j, (g, r) in enumerate(zip(got, ref)):
+        assert g.shape == (4224, 4224)
+        assert util.rel_err(g, r) < TOL, j
+        want = sum(float(img[:, :, f].astype(np.float64).sum()) * float(ks[j][:, :, f].astype(np.float64).sum()) for f in range(F))
+        assert abs(float(g.astype(np.float64).sum()) - want) / abs(want) < 1e-5
