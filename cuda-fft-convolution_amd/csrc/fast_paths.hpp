@@ -20,7 +20,9 @@ namespace fc {
 // RPW rows per workgroup chosen so that RPW * R1 * R2 = 192 stage-3 butterflies fill the lanes.
 //   4224 = 8 x 24 x 22 (cfg3; cfg4's 4160 window also runs on it): butterflies 528 / 176 / 192
 //   2112 = 8 x 12 x 22, 2 rows (cfg5):                            528 / 352 / 192
-//   1152 = 6 x  8 x 24, 4 rows (cfg2's 1088 window):              768 / 576 / 192
+//   1152 = 8 x 12 x 12, 2 rows (cfg2's 1088 window):              288 / 192 / 192   (round 3: was 6 x 8 x 24 with 4 rows per workgroup --
+//          160 registers, 3 waves per SIMD, 145 row groups; the lighter radix-12 stage 3 needs about 100 and twice as many,
+//          half as long workgroup steps fill the chip better: cfg2 196 -> 209 Gpx/s, 256 filters 321 -> 335)
 //   8448 = 16 x 24 x 22, 2 rows per workgroup of 768 threads (8192-sized images): 528 / 352 / 384 per row.  (Round 3: as
 //          one row per 384-thread workgroup only ONE workgroup was ever resident per CU -- at more than 128 VGPRs the
 //          hardware does not admit a second 6-wave workgroup, profiles/r03a_fused_roles_sq_counters.txt: 5.7 waves per CU;
@@ -50,8 +52,9 @@ namespace fc {
     X(2112, 8, 12, 22, 192, 2, 12)  \
     X(1536, 8, 12, 16, 192, 2, 3)   \
     X(1536, 8, 12, 16, 192, 2, 12)  \
-    X(1152, 6, 8, 24, 192, 4, 3)    \
-    X(1152, 6, 8, 24, 192, 4, 8)    \
+    X(1152, 8, 12, 12, 192, 2, 3)   \
+    X(1152, 8, 12, 12, 192, 2, 6)   \
+    X(1152, 8, 12, 12, 192, 2, 12)  \
     X(768, 4, 12, 16, 192, 4, 3)    \
     X(768, 4, 12, 16, 192, 4, 12)   \
     X(576, 4, 12, 12, 192, 4, 3)    \

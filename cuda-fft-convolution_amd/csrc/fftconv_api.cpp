@@ -366,6 +366,10 @@ struct fftconv_plan {
     bool prof_open = false;        // the last prof_begin recorded a start event
     // kernel column spectra of the first chunk already in A (fftconv_plan_prepare_kernels_packed)
     struct { const float* dk = nullptr; int n = 0, kh = 0, kw = 0; hipStream_t stream = nullptr; } prepared;   // (stream: the one A was produced on)
+    // fftconv_plan_prepare_kernels_packed DEFERRED: the kernels' column pass is launched by whichever comes first, the
+    // next set_image on the same stream (then in ONE launch with the image's column pass: launch_fast_cols_fwd_pair) or
+    // the next convolve / any call that must see it done (flush_pending_prepare)
+    struct { bool on = false; const float* dk = nullptr; int n = 0, na = 0, kh = 0, kw = 0; hipStream_t stream = nullptr; } deferred;
     std::vector<EventPair> pending;
     std::vector<EventPair> pool;
     double prof_ms[PK_COUNT] = {0, 0, 0, 0, 0};
@@ -609,6 +613,20 @@ int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh,
     return p->prof_end();
 }
 
+// the deferred kernel-column pass of fftconv_plan_prepare_kernels_packed, on its own (no set_image came first)
+int flush_pending_prepare(fftconv_plan* p) {
+    if (!p->deferred.on) return 0;
+    const auto pd = p->deferred;
+    p->deferred.on = false;
+    const hipStream_t cur = p->stream;
+    p->stream = pd.stream;                      // where the caller ordered the kernels' readiness
+    const int rc = launch_kernel_cols(p, pd.dk, 0, pd.na, pd.kh, pd.kw);
+    p->stream = cur;
+    if (rc) return rc;
+    p->prepared.dk = pd.dk; p->prepared.n = pd.n; p->prepared.kh = pd.kh; p->prepared.kw = pd.kw; p->prepared.stream = pd.stream;
+    return 0;
+}
+
 // Opt-in placement tuning of the intermediate (option tune_placement = k > 1).  On this memory system the
 // output kernel runs in one of two states, 4 % apart, and WHICH physical allocations hold the intermediate
 // and the maps decides it (profiles/r02x_placement_class_map.txt); nothing in user space can
@@ -715,6 +733,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     const Geometry& g = p->g;
     if (!p->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
     if (int rc = check_kernel_size(p, kh, kw)) return rc;
+    if (int rc = flush_pending_prepare(p)) return rc;
     const BatchSizes bs = batch_sizes(p, n, kw);
     const size_t per_a = bs.per_a;
     const int nbY = bs.nbY, nbA = bs.nbA;
@@ -1198,8 +1217,21 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
     // (with the fast row kernel the w-pass stores the spectrum directly in that kernel's register order)
     if (int rc = p->ensure_spectrum()) return rc;
     c32* sgen = p->spec();
+    if (p->deferred.on && p->deferred.stream != p->stream)
+        if (int rc = flush_pending_prepare(p)) return rc;
     if (int rc = p->prof_begin(PK_IMAGE_COLS, g.F)) return rc;
-    if (g.fast_fwd) {
+    if (g.fast_fwd && p->deferred.on) {
+        // the deferred kernel-column pass of fftconv_plan_prepare_kernels_packed and the image's column pass: ONE launch
+        const auto pd = p->deferred;
+        p->deferred.on = false;
+        FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dimg, (size_t)g.H * g.W, g.H, g.H, g.W, g.F, sgen,
+                                                (size_t)g.rows * g.s_pitch, g.s_pitch);
+        FastColsFwdArgs fk = fast_cols_fwd_args(g, p->d, pd.dk, (size_t)pd.kh * pd.kw, pd.kh, pd.kh, pd.kw, pd.na * g.F, p->A.p,
+                                                (size_t)g.rows * a_pitch_for(pd.kw), a_pitch_for(pd.kw));
+        FC_VERBOSE(p, "image columns (%d tiles) and the columns of %d kernels (%d tiles) in one launch", fa.ntiles, pd.na, fk.ntiles);
+        HIP_TRY(launch_fast_cols_fwd_pair(g.M, g.fast_cols.T, fa, fk, fast_cols_fwd_pruned_ok(g.fast_cols, pd.kh), p->num_cus, p->stream));
+        p->prepared.dk = pd.dk; p->prepared.n = pd.n; p->prepared.kh = pd.kh; p->prepared.kw = pd.kw; p->prepared.stream = p->stream;
+    } else if (g.fast_fwd) {
         FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dimg, (size_t)g.H * g.W, g.H, g.H, g.W, g.F, sgen,
                                                 (size_t)g.rows * g.s_pitch, g.s_pitch);
         HIP_TRY(launch_fast_cols_fwd(g.M, g.fast_cols.T, false, fa, p->num_cus, p->stream));
@@ -1336,8 +1368,15 @@ int fftconv_plan_prepare_kernels_packed(fftconv_plan* plan, int n_kernel, const 
     if (int rc = use_device(p)) return rc;
     if (int rc = check_kernel_size(p, kernel_h, kernel_w)) return rc;
     const BatchSizes bs = batch_sizes(p, n_kernel, kernel_w);
+    if (int rc = flush_pending_prepare(p)) return rc;      // an earlier request nobody consumed
     if (int rc = p->A.ensure(bs.per_a * bs.nbA)) return rc;
     p->prepared.dk = nullptr;
+    const bool timed_apart = p->profile && (p->profile_mask & ((1u << PK_KERNEL_COLS) | (1u << PK_IMAGE_COLS)));   // per-kind figures wanted
+    if (p->g.fast_fwd && !p->opt_flip_kernels && !timed_apart) {   // deferred: rides in the launch of the next image's column pass
+        p->deferred.on = true; p->deferred.dk = kernels_device; p->deferred.n = n_kernel; p->deferred.na = std::min(bs.nbA, n_kernel);
+        p->deferred.kh = kernel_h; p->deferred.kw = kernel_w; p->deferred.stream = p->stream;
+        return 0;
+    }
     if (int rc = launch_kernel_cols(p, kernels_device, 0, std::min(bs.nbA, n_kernel), kernel_h, kernel_w)) return rc;
     p->prepared.dk = kernels_device; p->prepared.n = n_kernel; p->prepared.kh = kernel_h; p->prepared.kw = kernel_w;
     p->prepared.stream = p->stream;
@@ -1396,7 +1435,12 @@ int fftconv_plan_set_stream(fftconv_plan* plan, void* hip_stream) {
     // (profile events already recorded stay valid: they are read later by fftconv_plan_get_profile,
     //  whichever stream they were recorded on -- collecting them here would block the host)
     // (prepared column spectra stay: they count again once the plan is back on the stream they were produced on --
-    //  the image transform of the multi-GPU step borrows the plan for a side stream and hands it back)
+    //  the image transform of the multi-GPU step borrows the plan for a side stream and hands it back; a DEFERRED
+    //  preparation is launched now, on the stream it was asked for)
+    if (!plan->tiled && plan->deferred.on) {
+        if (int rc = use_device(plan)) return rc;
+        if (int rc = flush_pending_prepare(plan)) return rc;
+    }
     plan->stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (plan->tiled) return fftconv_plan_set_stream(plan->tiled->sub, hip_stream);
     return 0;
@@ -1405,6 +1449,8 @@ int fftconv_plan_set_stream(fftconv_plan* plan, void* hip_stream) {
 int fftconv_plan_synchronize(fftconv_plan* plan) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     if (int rc = use_device(plan)) return rc;
+    if (!plan->tiled)
+        if (int rc = flush_pending_prepare(plan)) return rc;
     HIP_TRY(hipStreamSynchronize(plan->stream));
     return 0;
 }
@@ -1417,9 +1463,16 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         return fftconv_plan_set_option(plan->tiled->sub, name, value);
     }
     if (!strcmp(name, "tune_placement")) { plan->opt_tune_placement = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }
-    if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
-    if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; return 0; }
-    if (!strcmp(name, "profile")) { plan->profile = value != 0; return 0; }
+    if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
+    if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
+    if (!strcmp(name, "profile")) {
+        if (value != 0 && plan->deferred.on && (plan->profile_mask & ((1u << PK_KERNEL_COLS) | (1u << PK_IMAGE_COLS)))) {   // per-kind figures: the kernels' column pass is timed as a launch of its own
+            if (int rc = use_device(plan)) return rc;
+            if (int rc = flush_pending_prepare(plan)) return rc;
+        }
+        plan->profile = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "verbose")) { plan->opt_verbose = value != 0; return 0; }
     if (!strcmp(name, "profile_kinds")) { plan->profile_mask = value <= 0 ? ~0u : (unsigned)value; return 0; }
     if (!strcmp(name, "rows_group")) { plan->g.rows_group = value <= 0 ? -1 : (int)value; return 0; }
@@ -1442,7 +1495,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         plan->opt_region = value; plan->out_h = oh; plan->out_w = ow; plan->off_h = fh; plan->off_w = fw;
         return 0;
     }
-    if (!strcmp(name, "flip_kernels")) { plan->opt_flip_kernels = value != 0; plan->prepared.dk = nullptr; return 0; }
+    if (!strcmp(name, "flip_kernels")) { plan->opt_flip_kernels = value != 0; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
     if (!strcmp(name, "host_min_kb")) {
         if (value < 0 || value > (1 << 30)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);
         plan->opt_host_min_kb = value;

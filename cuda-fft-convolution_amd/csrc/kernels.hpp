@@ -35,6 +35,9 @@ hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s);
 hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_fast_cols_fwd(int M, int T, bool pruned, const FastColsFwdArgs& a, int num_cus, hipStream_t s);
+// image columns (full variant) and kernel columns (pruned or full) of one plan in ONE launch (kernels_cols_fwd.hip)
+hipError_t launch_fast_cols_fwd_pair(int M, int T, const FastColsFwdArgs& image, const FastColsFwdArgs& kernels, bool kernels_pruned,
+                                     int num_cus, hipStream_t s);
 hipError_t launch_cols_c2r(const ColsC2RArgs& a, int tiles, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 
 }  // namespace fc

@@ -891,3 +891,65 @@ def test_full_size_five_feature_maps_vs_oracle(fc, oracle):
         assert util.rel_err(g, r) < TOL, j
         want = sum(float(img[:, :, f].astype(np.float64).sum()) * float(ks[j][:, :, f].astype(np.float64).sum()) for f in range(F))
         assert abs(float(g.astype(np.float64).sum()) - want) / abs(want) < 1e-5
+
+
+def test_deferred_kernel_preparation_in_every_order(fc, oracle):
+    """fftconv_plan_prepare_kernels_packed only records the request; the kernels' column pass runs in ONE launch
+    with the next image's column pass (set_image on the same stream) or, if none comes, at the convolve.  Every
+    order of the calls must give the maps of a plan that never prepared anything."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    for (H, W, F, kh, kw, n) in [(256, 256, 1, 31, 31, 3), (300, 260, 2, 15, 13, 5), (1024, 1024, 1, 63, 63, 4)]:
+        img, ks = util.synth(101, H, W, F, kh, kw, n)
+        img2, ks2 = util.synth(102, H, W, F, kh, kw, n)
+        ref, ref2, ref12 = oracle.conv_fft(img, kh, kw, ks), oracle.conv_fft(img2, kh, kw, ks), oracle.conv_fft(img2, kh, kw, ks2)
+        pack = lambda kk: torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in kk]))).to(dev)
+        img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (2, 1, 0)))).to(dev)
+        img2_d = torch.from_numpy(np.ascontiguousarray(np.transpose(img2, (2, 1, 0)))).to(dev)
+        k_d, k2_d = pack(ks), pack(ks2)
+        side = torch.cuda.Stream(dev)
+        with fc.Plan(H, W, F, kh, kw) as p:
+            out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+
+            def check(want):
+                p.synchronize()
+                for j, r in enumerate(want):
+                    assert util.rel_err(out[j].cpu().numpy().T, r) < TIGHT, (H, W, j)
+
+            # prepare -> set_image (merged launch) -> convolve
+            p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+            p.set_image_device(img_d.data_ptr())
+            p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+            check(ref)
+            # prepare -> convolve (no image in between: flushed by the convolve), image spectrum reused
+            out.zero_()
+            p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+            p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+            check(ref)
+            # prepared for one set of kernels, convolved with another: the preparation is not used
+            out.zero_()
+            p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+            p.set_image_device(img2_d.data_ptr())
+            p.convolve_packed_device(n, k2_d.data_ptr(), kh, kw, out.data_ptr())
+            check(ref12)
+            # two preparations in a row, then a stream change before the image (the request is flushed on its own stream)
+            out.zero_()
+            p.prepare_kernels_packed_device(n, k2_d.data_ptr(), kh, kw)
+            p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+            torch.cuda.synchronize(dev)
+            p.set_stream(side.cuda_stream)
+            p.set_image_device(img2_d.data_ptr())
+            p.synchronize()
+            p.set_stream(0)
+            p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+            check(ref2)
+            # with per-kind profiling the two passes are separate launches and both are counted
+            p.set_option("profile", 1)
+            p.profile(reset=True)
+            p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+            p.set_image_device(img_d.data_ptr())
+            p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+            check(ref)
+            prof = p.profile(reset=True)
+            assert prof["kernel_cols"]["launches"] == 1 and prof["image_cols"]["launches"] == 1
+            p.set_option("profile", 0)
