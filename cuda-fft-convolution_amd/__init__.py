@@ -12,6 +12,10 @@ mirror of the reference's MATLAB call surface so tests read like the reference's
 Arrays follow MATLAB conventions: ``data`` is H x W x F, kernels are kh x kw x F, every result is
 the full FFT_H x FFT_W window (not cropped).  There is no CPU fallback: if the HIP library is
 missing or no GPU is present the compute calls raise.
+
+Environment (this stub only; libfftconv.so itself reads none): FFTCONV_LIB = path of an alternate
+build of the library (A/B runs, tools/build_variant.sh); FFTCONV_NO_TORCH_RUNTIME = 1 skips the
+preload of PyTorch's bundled HIP runtime (see _preload_hip_runtime).
 """
 import ctypes
 import os
