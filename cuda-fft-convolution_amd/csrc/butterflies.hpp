@@ -69,9 +69,13 @@ constexpr bool is_prime(int r) { return r >= 2 && smallest_factor(r) == r && r !
 template <int R, int SGN, class Enable = void>
 struct Dft;
 
+// run_nz<NZ>(v): the same transform when v[NZ..R) are structural zeros (the zero padding of a short kernel row seen by
+// the middle stage of a pruned transform): the composite form skips the butterflies whose inputs are a single value.
 template <int SGN>
 struct Dft<1, SGN, void> {
     static FC_HD void run(c32 (&)[1]) {}
+    template <int NZ>
+    static FC_HD void run_nz(c32 (&)[1]) {}
 };
 
 template <int SGN>
@@ -80,6 +84,11 @@ struct Dft<2, SGN, void> {
         c32 a = v[0], b = v[1];
         v[0] = a + b;
         v[1] = a - b;
+    }
+    template <int NZ>
+    static FC_HD void run_nz(c32 (&v)[2]) {
+        if constexpr (NZ <= 1) v[1] = v[0];
+        else run(v);
     }
 };
 
@@ -92,6 +101,20 @@ struct Dft<4, SGN, void> {
         v[1] = add_j<SGN>(s1, d);
         v[2] = s0 - s2;
         v[3] = sub_j<SGN>(s1, d);
+    }
+    template <int NZ>
+    static FC_HD void run_nz(c32 (&v)[4]) {
+        if constexpr (NZ <= 1) {
+            v[1] = v[0]; v[2] = v[0]; v[3] = v[0];
+        } else if constexpr (NZ == 2) {     // v[2] = v[3] = 0
+            const c32 a = v[0], b = v[1];
+            v[0] = a + b;
+            v[1] = add_j<SGN>(a, b);
+            v[2] = a - b;
+            v[3] = sub_j<SGN>(a, b);
+        } else {
+            run(v);
+        }
     }
 };
 
@@ -132,6 +155,11 @@ struct DftOddPrime {
 template <int R, int SGN>
 struct Dft<R, SGN, std::enable_if_t<(R >= 3) && (R % 2 == 1) && is_prime(R)>> {
     static FC_HD void run(c32 (&v)[R]) { DftOddPrime<R, SGN>::run(v); }
+    template <int NZ>
+    static FC_HD void run_nz(c32 (&v)[R]) {
+        if constexpr (NZ <= 1) static_for<1, R>([&](auto k_) { v[decltype(k_)::value] = v[0]; });
+        else DftOddPrime<R, SGN>::run(v);
+    }
 };
 
 // Composite R = R1*R2, decimation in frequency in registers:
@@ -170,9 +198,48 @@ struct DftCT {
     }
 };
 
+// The same with v[NZ..R) zero, NZ <= R2: every first-stage butterfly has the single input v[b] (its R1 outputs are
+// copies), and only the first NZ inputs of every second-stage transform are non-zero.
+template <int R1, int R2, int SGN, int NZ>
+struct DftCTnz {
+    static constexpr int R = R1 * R2;
+    static_assert(NZ >= 1 && NZ <= R2, "pruned composite: the non-zero inputs must lie in the first sub-block");
+    static FC_HD void run(c32 (&v)[R]) {
+        c32 y[R];
+        static_for<0, NZ>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            const c32 x = v[b];
+            static_for<0, R1>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                y[c * R2 + b] = mul_root<R, b * c, SGN>(x);
+            });
+        });
+        static_for<0, R1>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            c32 t[R2];
+            static_for<0, R2>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                if constexpr (b < NZ) t[b] = y[c * R2 + b];
+                else t[b] = mk(0.f, 0.f);
+            });
+            Dft<R2, SGN>::template run_nz<NZ>(t);
+            static_for<0, R2>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
+                v[c + R1 * k] = t[k];
+            });
+        });
+    }
+};
+
 template <int R, int SGN>
 struct Dft<R, SGN, std::enable_if_t<(R > 4) && !is_prime(R)>> {
-    static FC_HD void run(c32 (&v)[R]) { DftCT<smallest_factor(R), R / smallest_factor(R), SGN>::run(v); }
+    static constexpr int F1 = smallest_factor(R), F2 = R / smallest_factor(R);
+    static FC_HD void run(c32 (&v)[R]) { DftCT<F1, F2, SGN>::run(v); }
+    template <int NZ>
+    static FC_HD void run_nz(c32 (&v)[R]) {
+        if constexpr (NZ >= 1 && NZ <= F2) DftCTnz<F1, F2, SGN, NZ>::run(v);
+        else DftCT<F1, F2, SGN>::run(v);
+    }
 };
 
 }  // namespace fc

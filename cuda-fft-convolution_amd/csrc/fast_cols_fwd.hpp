@@ -137,7 +137,8 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
                             v[a] = p[a * R3];
                         }
                     });
-                    Dft<R2, -1>::run(v);
+                    if constexpr (PRUNED) Dft<R2, -1>::template run_nz<NZ2>(v);
+                    else Dft<R2, -1>::run(v);
                     p[0] = v[0];
                     static_for<1, R2>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;

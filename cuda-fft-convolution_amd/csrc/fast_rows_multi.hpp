@@ -141,7 +141,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         if constexpr (a < NZ2) v[a] = (a * R3 + b < kw) ? p[a * R3] : mk(0.f, 0.f);
                         else v[a] = mk(0.f, 0.f);
                     });
-                    Dft<R2, -1>::run(v);
+                    Dft<R2, -1>::template run_nz<NZ2>(v);   // inputs a >= NZ2 are structural zeros
                     p[0] = v[0];
                     static_for<1, R2>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;
