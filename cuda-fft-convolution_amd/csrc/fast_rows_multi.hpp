@@ -157,17 +157,24 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         ctx.phase([&](int t, State& st) {
             const int rr = t / C::NB3, q = t - rr * C::NB3;
             if (rr < RPW) {
-                if constexpr (MULTIF) {   // this feature's image-spectrum row: in flight during the butterfly
+                // MULTIF: this feature's image-spectrum row.  Only its first FC_MULTIF_S_EARLY register pairs are requested
+                // ahead of the forward butterfly, the rest right after it: with the whole row in flight beside the
+                // radix-22 butterfly (its in-register composite form needs ~70 registers of its own) and the feature
+                // sum, the kernel spilled 27-50 registers at L = 4224, differently in every translation unit, and a
+                // scratch reload shares the in-order memory counter with these very loads (59.7 -> 56.6 us per map at
+                // F = 4 with none early and no spills, profiles/r03i_f4_image_row_load_placement.txt)
+                constexpr int S_EARLY = (FC_MULTIF_S_EARLY < R3 / 2) ? FC_MULTIF_S_EARLY : R3 / 2;
+                if constexpr (MULTIF && (0) < (S_EARLY)) {
                     if (row0 + rr < rows) {
                         const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(row0 + rr) * g.s_pitch;
-                        static_for<0, R3 / 2>([&](auto h_) {
+                        static_for<(0), (S_EARLY)>([&](auto h_) {
                             constexpr int h = decltype(h_)::value;
                             c32x2 w = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
                             st.s[2 * h] = w.a;
                             st.s[2 * h + 1] = w.b;
                         });
                     } else {
-                        static_for<0, R3>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
+                        static_for<2 * (0), 2 * (S_EARLY)>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
                     }
                 }
                 c32* p = lds + rr * L + q * R3;
@@ -195,6 +202,19 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     FC_SCHED_FENCE();
                 }
                 Dft<R3, -1>::run(v);
+                if constexpr (MULTIF && (S_EARLY) < (R3 / 2)) {
+                    if (row0 + rr < rows) {
+                        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(row0 + rr) * g.s_pitch;
+                        static_for<(S_EARLY), (R3 / 2)>([&](auto h_) {
+                            constexpr int h = decltype(h_)::value;
+                            c32x2 w = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
+                            st.s[2 * h] = w.a;
+                            st.s[2 * h + 1] = w.b;
+                        });
+                    } else {
+                        static_for<2 * (S_EARLY), 2 * (R3 / 2)>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
+                    }
+                }
                 if constexpr (!MULTIF) {
                     static_for<0, R3>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;

@@ -9,7 +9,7 @@
 #if !defined(FC_INSTRUMENT)
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_ROWS1_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_NT_SLOADS) ||              \
-    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED)
+    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -46,6 +46,12 @@
 #endif
 #ifndef FC_ROWSM_DBG
 #define FC_ROWSM_DBG 0           // multi-map kernel, wrong results: 1 P5 without its LDS reads and stage-1 arithmetic, 2 no stores
+#endif
+// F > 1 walk: register pairs of the image-spectrum row requested BEFORE the forward butterfly (0 .. R3 / 2; the rest
+// right after it).  All 11 early (rounds 1-2): 27-50 spilled registers at L = 4224; 0 / 4 / 8 early: none, and
+// 56.7 / 53.2 / 54.6 us per map at F = 4 on one box (profiles/r03i_f4_image_row_load_placement.txt)
+#ifndef FC_MULTIF_S_EARLY
+#define FC_MULTIF_S_EARLY 4
 #endif
 #ifndef FC_ROWS_TIMELINE
 #define FC_ROWS_TIMELINE 0       // 1: one workgroup stamps the wall clock at every phase boundary (tools/rows_timeline.py)

@@ -74,7 +74,8 @@ struct Geometry {
         // stay there only while few row groups are in flight per XCD, i.e. while many workgroups share a row
         // group: short walks (measured optimum 4-6 maps at F <= 8, 2 at F = 32; tools/f_group.py,
         // profiles/r02x_f_walk_length.txt: 16-map walks fetch 205 MB per map at F = 8, 4-map walks 62)
-        return std::min(g1, std::max(2, std::min(6, 32 / F)));
+        // (round 3, spill-free kernel: 3 / 4 / 6 / 8 / 12 maps at F = 4: 56.2 / 55.1 / 56.9 / 56.7 / 60.0 us per map)
+        return std::min(g1, std::max(2, std::min(4, 32 / F)));
     }
     int rows_group_auto(int nmaps, int num_cus) const {
         const long groups = (rows + fast_rows.RPW - 1) / fast_rows.RPW;

@@ -273,9 +273,10 @@ def test_hot_kernels_do_not_spill():
     assert not bad, bad
     multi_f = {k: v for k, v in rep.items() if "k_fast_rows_multi_fI" in k}
     assert multi_f and all(v["occ"] >= 3 for v in multi_f.values())
-    # the cfg3-sized transform (4224 = 8.24.22) of the F > 1 walk, in its LINEAR form (what the plan launches): <= 32 spilled
-    # registers wherever it is compiled; the whole family stays under 128
-    l4224 = [v["spill"] for k, v in multi_f.items() if "Li4224ELi8ELi24ELi22ELi192ELi1E" in k and k.split("EEE")[1].endswith("Lb1E")] or \
-            [v["spill"] for k, v in multi_f.items() if "Li4224ELi8ELi24ELi22ELi192ELi1E" in k]
-    assert l4224 and min(l4224) <= 32, l4224
-    assert max(v["spill"] for v in multi_f.values()) <= 128
+    # the cfg3-sized transform (4224 = 8.24.22) of the F > 1 walk: spill-free since round 3 (only part of the image-spectrum row
+    # is requested ahead of the radix-22 butterfly); configurations with two or four rows per workgroup still spill, under 64
+    l4224 = {k: v["spill"] for k, v in multi_f.items() if "Li4224ELi8ELi24ELi22ELi192ELi1E" in k}
+    linear = [v for k, v in l4224.items() if "ELb1EEEv" in k]       # the LINEAR store form: what a default plan launches
+    assert len(linear) == 3 and max(linear) == 0, l4224
+    assert max(l4224.values()) <= 16, l4224
+    assert max(v["spill"] for v in multi_f.values()) <= 64
