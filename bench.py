@@ -599,6 +599,19 @@ def main():
                                   "algorithmic_bytes_per_launch": ab[dom] * per[dom]["units_per_launch"],
                                   "avg_launch_ms": per[dom]["avg_ms"]}
         result.update(extras)
+        if world > 1 and not streamed and cfg == "cfg4" and nf_total == CONFIGS["cfg4"][5] and not args.weak:
+            # the driver's N = 1 run is the headline (cfg3); the strong-scaling denominator of THIS workload on one GPU is
+            # the newest committed single-GPU run of it (python bench.py --config cfg4)
+            import glob
+            den = sorted(glob.glob(os.path.join(ROOT, "profiles", "*cfg4_1024_filters_1gpu_denominator.json")))
+            if den:
+                try:
+                    dj = json.loads(open(den[-1]).read().strip().splitlines()[-1])
+                    result["same_workload_1gpu"] = {"value": dj["value"], "ms_per_step": dj["ms_per_step"], "unit": dj["unit"],
+                                                    "source": os.path.relpath(den[-1], ROOT),
+                                                    "speedup": value / dj["value"]}
+                except Exception:
+                    pass
         if use_dist:
             result["config"]["backend"] = backend + (" (all ranks on cuda:0: rehearsal)" if args.share_gpu else "")
         if cpu is not None:
