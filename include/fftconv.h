@@ -251,7 +251,8 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             allocations of it are timed with the output kernel writing into the caller's map buffer and
  *             the fastest is kept -- on MI355X the output kernel runs 4 % faster or slower depending on which
  *             physical allocations hold its two buffers; blocking, ~70 ms, once per
- *             allocation; 0 (default): off),
+ *             allocation; transient device memory while it runs: k intermediates plus k - 1 spacer allocations of at
+ *             most 12 GiB (an eighth of what is free) each; skipped inside a stream capture; 0 (default): off),
  *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
  *          "profile" (1: time every kernel launch with HIP events on the plan's stream),
  *          "profile_kinds" (bit mask over the indices of fftconv_profile: only those kinds are timed
