@@ -87,7 +87,12 @@ struct Geometry {
             const long slots = (long)num_cus * 4, total = groups * nmaps;
             return total > slots ? (int)std::min<long>(nmaps, (total + slots - 1) / slots) : 1;
         }
-        return (int)std::max<long>(1, std::min<long>(16, std::min<long>(g, nmaps)));
+        long w = std::max<long>(1, std::min<long>(16, std::min<long>(g, nmaps)));
+        // between four and eight rounds of one-map workgroups: walks of two still leave two rounds of workgroups and pay
+        // the twiddle fill, the image-spectrum row and the store drain once per two maps (cfg2, 16 kernels on 1152-point
+        // rows: 4624 one-map workgroups 84.6 us per step, 2312 two-map walks 81.8, four-map walks 82.6)
+        if (w == 1 && nmaps >= 2 && groups * nmaps >= 2 * (long)num_cus * 4) w = 2;
+        return (int)w;
     }
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {
