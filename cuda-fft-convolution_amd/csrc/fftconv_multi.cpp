@@ -239,11 +239,13 @@ int broadcast_spectrum_rccl(fftconv_multi* m, void* src, size_t bytes) {
     for (int g = 1; g < n; g++)
         if (int rc = fftconv_plan_spectrum(m->plan[g], &dst[g], nullptr)) return rc;
     int r = api.GroupStart();
-    for (int g = 0; g < n && r == 0; g++) {
-        if (hipSetDevice(m->dev[g]) != hipSuccess) return api_fail(FFTCONV_ERR_HIP, "hipSetDevice(%d) failed", m->dev[g]);
+    int bad_device = -1;
+    for (int g = 0; g < n && r == 0 && bad_device < 0; g++) {
+        if (hipSetDevice(m->dev[g]) != hipSuccess) { bad_device = m->dev[g]; break; }
         r = api.Broadcast(src, dst[g], bytes, kNcclChar, 0, m->comms[g], m->stream[g]);
     }
-    const int r2 = api.GroupEnd();
+    const int r2 = api.GroupEnd();      // always closed, whatever happened inside
+    if (bad_device >= 0) return api_fail(FFTCONV_ERR_HIP, "hipSetDevice(%d) failed", bad_device);
     if (r == 0) r = r2;
     if (r != 0) return api_fail(FFTCONV_ERR_HIP, "ncclBroadcast of the image spectrum failed: %s", api.GetErrorString ? api.GetErrorString(r) : "error");
     for (int g = 1; g < n; g++)
