@@ -1128,6 +1128,14 @@ int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feat
             if ((rc = cp(p->fc_pair_row_of.p, ft.pair_row_of.data(), ft.pair_row_of.size() * sizeof(int)))) break;
             p->d.fc_pair_row_of = p->fc_pair_row_of.p;
         }
+        if (p->g.fast_rows.ok && p->g.F == 1) {   // resident workgroups per CU of the multi-map row kernel: what rows_group_auto deals over
+            FastRowsArgs qa = fast_rows_args(p->g, p->d, nullptr, p->g.max_kw, nullptr, nullptr);
+            int per_cu = 0;
+            if (fast_rows_multi_wgs_per_cu(p->g.Lw, fast_rows_nz2(p->g, std::min(p->g.max_kw, p->g.fast_rows.max_kw)), qa, &per_cu) == hipSuccess && per_cu > 0)
+                p->g.rows_slots_per_cu = per_cu;
+            else
+                (void)hipGetLastError();
+        }
         if (p->g.fast_rows.ok) {
             const FastRowsTables& fr = p->t.fr;
             if ((rc = p->fr_tw1.ensure(fr.tw1.size()))) break;
@@ -1524,6 +1532,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "tuned_candidates")) { *value = plan->tuned_candidates; return 0; }
     if (!strcmp(name, "tuned_best")) { *value = plan->tuned_best; return 0; }
     if (!strcmp(name, "rows_group")) { *value = plan->g.rows_group; return 0; }
+    if (!strcmp(name, "rows_slots_per_cu")) { *value = plan->g.rows_slots_per_cu; return 0; }   // read-only: resident row workgroups per CU
     if (!strcmp(name, "host_stream")) { *value = plan->opt_host_stream; return 0; }
     if (!strcmp(name, "host_min_kb")) { *value = plan->opt_host_min_kb; return 0; }
     if (!strcmp(name, "output_region")) { *value = plan->opt_region; return 0; }

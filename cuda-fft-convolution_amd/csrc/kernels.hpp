@@ -33,6 +33,8 @@ hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels
 hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s);
 // several maps per workgroup (fast_rows_multi.hpp, F = 1): kernels_per_wg consecutive kernels share one fetch of the image-spectrum row
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s);
+// how many workgroups of that kernel a CU holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)
+hipError_t fast_rows_multi_wgs_per_cu(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu);
 hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_fast_cols_fwd(int M, int T, bool pruned, const FastColsFwdArgs& a, int num_cus, hipStream_t s);
 // image columns (full variant) and kernel columns (pruned or full) of one plan in ONE launch (kernels_cols_fwd.hip)

@@ -34,6 +34,27 @@ __global__ void __launch_bounds__(Cfg::NT, 3) k_fast_rows_multi_f(FastRowsArgs a
     fast_rows_multi_body<Cfg, NZ2, LINEAR, true>(ctx, reinterpret_cast<c32*>(fc_smem), a, group, kernel0, nk, rows);
 }
 
+// resident workgroups per CU of the F = 1 multi-map kernel a launch with these arguments would use (the runtime's
+// occupancy calculator: registers, LDS, waves)
+struct FastRowsMultiOccupancy {
+    const FastRowsArgs& a;
+    int result = 0;
+    hipError_t err = hipSuccess;
+    template <class Cfg, int NZ2>
+    void go() {
+        if (fast_rows_multi_linear(a, Cfg::L, Cfg::m1)) query<Cfg, NZ2, true>();
+        else query<Cfg, NZ2, false>();
+    }
+    template <class Cfg, int NZ2, bool LINEAR>
+    void query() {
+        static LdsAttrMask attr_mask{0};
+        err = ensure_lds_attr(k_fast_rows_multi<Cfg, NZ2, LINEAR>, attr_mask);
+        if (err != hipSuccess) return;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&result, reinterpret_cast<const void*>(k_fast_rows_multi<Cfg, NZ2, LINEAR>), Cfg::NT,
+                                                           (size_t)Cfg::LDS_ELEMS * sizeof(c32));
+    }
+};
+
 struct FastRowsMultiLauncher {
     const FastRowsArgs& a;
     int rows, kernels, per_wg;
@@ -67,6 +88,13 @@ struct FastRowsMultiLauncher {
 };
 
 }  // namespace
+
+hipError_t fast_rows_multi_wgs_per_cu(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu) {
+    FastRowsMultiOccupancy q{a};
+    if (!fast_rows_dispatch(L, nz2, q)) return hipErrorInvalidValue;
+    if (q.err == hipSuccess && wgs_per_cu) *wgs_per_cu = q.result;
+    return q.err;
+}
 
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s) {
     if (rows <= 0 || kernels <= 0) return hipSuccess;

@@ -77,22 +77,22 @@ struct Geometry {
         // (round 3, spill-free kernel: 3 / 4 / 6 / 8 / 12 maps at F = 4: 56.2 / 55.1 / 56.9 / 56.7 / 60.0 us per map)
         return std::min(g1, std::max(2, std::min(4, 32 / F)));
     }
+    int rows_slots_per_cu = 4; // resident workgroups of the multi-map row kernel per CU (the plan asks the runtime: light
+                               // configurations hold 5-6, the 4224-point one 4)
+    // Maps per workgroup of the multi-map row kernel for a launch of nmaps.  Large launches (eight or more rounds of
+    // one-map workgroups): as many as leaves >= 4 rounds, at most 16 -- the walk amortises the image-spectrum row, the
+    // launch and the store drain, but a grid that no longer fills the chip loses more than that.  Small launches: the
+    // shortest walk whose FULL walks are all resident at once (the remainder walk of every row group, launched last,
+    // fills the slots they leave and the first ones to free up) -- cfg2, 289 row groups x 16 maps on 1536 slots: walks of
+    // 1 / 2 / 3 / 4 / 5 maps take 84.6 / 81.4 / 79.2 / 82.6 / 83.6 us per step; 3 = 1445 full walks + 289 single maps.
     int rows_group_auto(int nmaps, int num_cus) const {
         const long groups = (rows + fast_rows.RPW - 1) / fast_rows.RPW;
-        const long g = groups * nmaps / ((long)num_cus * 16);
-        if (g < 1) {
-            // small launches: more workgroups than resident slots (4 per CU) but not four rounds of them --
-            // walk just enough maps per workgroup that ONE round covers the launch (cfg2: 2320 -> 870
-            // workgroups, 2.9 -> 2.5 us per map) instead of leaving a mostly empty last round
-            const long slots = (long)num_cus * 4, total = groups * nmaps;
-            return total > slots ? (int)std::min<long>(nmaps, (total + slots - 1) / slots) : 1;
-        }
-        long w = std::max<long>(1, std::min<long>(16, std::min<long>(g, nmaps)));
-        // between four and eight rounds of one-map workgroups: walks of two still leave two rounds of workgroups and pay
-        // the twiddle fill, the image-spectrum row and the store drain once per two maps (cfg2, 16 kernels on 1152-point
-        // rows: 4624 one-map workgroups 84.6 us per step, 2312 two-map walks 81.8, four-map walks 82.6)
-        if (w == 1 && nmaps >= 2 && groups * nmaps >= 2 * (long)num_cus * 4) w = 2;
-        return (int)w;
+        const long slots = (long)num_cus * std::max(1, rows_slots_per_cu), total = groups * nmaps;
+        if (total >= 8 * slots) return (int)std::max<long>(1, std::min<long>(16, std::min<long>(total / (4 * slots), nmaps)));
+        if (total <= slots) return 1;        // everything resident at once
+        for (int w = 2; w <= std::min(16, nmaps); w++)
+            if (groups * (nmaps / w) <= slots) return w;
+        return std::min(16, nmaps);
     }
     size_t spectrum_elems() const { return (size_t)F * rows * s_pitch; }
     size_t y_elems_per_kernel() const {

@@ -280,8 +280,9 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             demoCudaConvolutionFFT.m:63-69 done here instead of in MATLAB; the reference keeps a
  *             conjugate-product variant commented out, src/cudaConvFFTData.cuh:42-45,63). */
 int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
-/* Current value of an option, plus two read-only ones about the last placement tuning:
- * "tuned_candidates" (allocations tried) and "tuned_best" (index of the one kept). */
+/* Current value of an option, plus read-only ones: "tuned_candidates" (allocations tried by the last placement tuning)
+ * and "tuned_best" (index of the one kept), "blockwise" (blocks of a block-wise plan, 0 = one pass),
+ * "rows_slots_per_cu" (workgroups of the multi-map row kernel a CU holds at once: what the walk length is chosen for). */
 int fftconv_plan_get_option(fftconv_plan *plan, const char *name, long *value);
 
 typedef struct fftconv_profile {
