@@ -71,6 +71,10 @@ struct FastColsArgs {
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
     const PairEntry* pairs;  // NPE entries: [0] DC/Nyquist, [k] pair (k, M-k), [M/2] middle (w = w_N^k)
     unsigned long long* timeline;  // FC_COLS_TIMELINE builds only: per-phase wall-clock stamps of workgroup 0 (else unused)
+    // SLICED launches (small transforms whose last round of tiles would leave most workgroups idle): `ntiles` covers the
+    // full rounds only; the `tail_tiles` tiles from `tail_first` on are cut into 1 << slice_shift column slices each and
+    // dealt one slice per workgroup.  All three are 0 otherwise.
+    int tail_first, tail_tiles, slice_shift;
 };
 
 template <class C>
@@ -95,8 +99,13 @@ struct ColPairState {
 // and merges them in registers on the way into LDS, so the pair pass (and its barrier) disappears.
 // A template parameter so that each variant carries only its own address arithmetic (the kernel
 // sits right at the 168-VGPR budget of 3 waves per SIMD).
-template <class C, bool TILED, class Ctx>
+// SLICED (tiled intermediate only, instantiated for the small transforms only): after its full tiles a workgroup
+// takes one column SLICE of a tile of the last, partial round -- the same phases with the lanes of the other columns
+// switched off -- so that round costs a fraction of a tile time instead of a whole one (cfg2: 16 maps x 68 tiles = 1088
+// tiles on 256 workgroups are 4 full rounds + 64 tiles; as 256 quarter tiles the fifth round moves a quarter of the bytes).
+template <class C, bool TILED, bool SLICED = false, class Ctx>
 FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
+    static_assert(!SLICED || TILED, "column slices exist for the tiled intermediate only");
     constexpr bool PLAND = TILED;
     constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
     constexpr int T2 = T / 2;
@@ -114,13 +123,27 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     // run of tiles.  Falls back to the plain order when nwg is not a multiple of 8.
     const int per_xcd = nwg / 8;
     const int wg_x = (nwg % 8 == 0) ? (wg % 8) * per_xcd + wg / 8 : wg;
-    auto tile_of = [&](int it) -> int { return it * nwg + wg_x; };   // it-th tile of this workgroup
+    // it-th tile of this workgroup; SLICED: behind the full rounds (g.ntiles tiles) comes this workgroup's slice of a tail
+    // tile, reported as tile index >= g.ntiles (cur_lo / cur_hi below say which columns of it are this workgroup's)
+    const int full_rounds = SLICED ? g.ntiles / nwg : 0;
+    const int n_total = SLICED ? g.ntiles + g.tail_tiles : g.ntiles;     // tile indices below this exist
+    auto tile_of = [&](int it) -> int {
+        if constexpr (SLICED) {
+            if (it == full_rounds) return (wg_x < (g.tail_tiles << g.slice_shift)) ? g.tail_first + (wg_x >> g.slice_shift) : n_total;
+            if (it > full_rounds) return n_total;
+        }
+        return it * nwg + wg_x;
+    };
+    // columns [lo, hi) of tile it that this workgroup transforms (the whole tile unless it is the slice round)
+    auto cols_lo = [&](int it) -> int { return (SLICED && it == full_rounds) ? (wg_x & ((1 << g.slice_shift) - 1)) * (T >> g.slice_shift) : 0; };
+    auto cols_hi = [&](int it) -> int { return (SLICED && it == full_rounds) ? cols_lo(it) + (T >> g.slice_shift) : T; };
     const int first_tile = tile_of(0);
+    [[maybe_unused]] int cur_lo = cols_lo(0), cur_hi = cols_hi(0), nxt_lo = 0, nxt_hi = T;
 
     // part: 0 = the whole gather; 1 / 2 (mode 3) = its first / second half of rounds -- a CU cannot
     // keep a whole tile (135 KB) of loads in flight, so issuing it in one go stalls the waves in
     // the issue itself; the second half is issued one phase later, while the first drains
-    auto issue_gather = [&](int t, State& st, int tile, auto part_) {
+    auto issue_gather = [&](int t, State& st, int tile, auto part_, [[maybe_unused]] int c_lo, [[maybe_unused]] int c_hi) {
         constexpr int part = decltype(part_)::value;
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
@@ -134,7 +157,9 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             static_for<RB, RE>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int e = t + NT * r;
-                if (e < State::NPU) {
+                bool mine = e < State::NPU;
+                if constexpr (SLICED) mine = mine && 2 * (e % T2) >= c_lo && 2 * (e % T2) < c_hi;
+                if (mine) {
                     const c32* pr = Yt + ((size_t)(2 * (e / T2)) << g.y_tile_shift) + 2 * (e % T2);
                     if constexpr (!(FC_COLS_DBG & 4)) {
                         FC_STREAM_LOAD16(st.pa[r], pr);
@@ -152,12 +177,14 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             if (t < T2) st.pre_ny = *reinterpret_cast<const c32x2*>(Y + g.rowoff[M] + 2 * t);
         }
     };
-    auto land_gather = [&](int t, State& st) {
+    auto land_gather = [&](int t, State& st, [[maybe_unused]] int c_lo, [[maybe_unused]] int c_hi) {
         if constexpr (PLAND) {
             static_for<0, State::RNDU>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 const int e = t + NT * r;
-                if (e < State::NPU) {
+                bool mine = e < State::NPU;
+                if constexpr (SLICED) mine = mine && 2 * (e % T2) >= c_lo && 2 * (e % T2) < c_hi;
+                if (mine) {
                     const int k = e / T2, t2 = e % T2;
                     const unsigned pp = ppos[k];
                     const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
@@ -228,26 +255,27 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             constexpr int r = decltype(r_)::value;
             st.off[r] = g.rowoff[(t + NT * r) / T2];
         });
-        if (first_tile < g.ntiles) issue_gather(t, st, first_tile, IC<0>{});
+        if (first_tile < n_total) issue_gather(t, st, first_tile, IC<0>{}, cur_lo, cur_hi);
     });
     // (the landing of mode 3 reads the tables written above: it needs the barrier in between)
-    if (first_tile < g.ntiles) ctx.phase([&](int t, State& st) { land_gather(t, st); });
+    if (first_tile < n_total) ctx.phase([&](int t, State& st) { land_gather(t, st, cur_lo, cur_hi); });
 
     for (int it = 0;; it++) {
         const int tile = tile_of(it);
-        if (tile >= g.ntiles) break;
+        if (tile >= n_total) break;
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
         const int next = tile_of(it + 1);
+        if constexpr (SLICED) { cur_lo = cols_lo(it); cur_hi = cols_hi(it); nxt_lo = cols_lo(it + 1); nxt_hi = cols_hi(it + 1); }
         FC_COLS_STAMP(0);
 
         // C1: issue the next tile's gather (lands after C4), then merge the half spectrum of
         // this tile into the packed complex sequence, in place (table driven)
         if constexpr (PLAND) ctx.phase_nosync([&](int t, State& st) {
-            if (next < g.ntiles) issue_gather(t, st, next, IC<(PLAND && FC_COLS_SPLIT_GATHER) ? 1 : 0>{});
+            if (next < n_total) issue_gather(t, st, next, IC<(PLAND && FC_COLS_SPLIT_GATHER) ? 1 : 0>{}, nxt_lo, nxt_hi);
         });
         else ctx.phase([&](int t, State& st) {
-            if (next < g.ntiles) issue_gather(t, st, next, IC<0>{});
+            if (next < n_total) issue_gather(t, st, next, IC<0>{}, nxt_lo, nxt_hi);
             if constexpr (!(FC_COLS_DBG & 1))
             FC_NOUNROLL
             for (int r = 0; r < C::RNDP; r++) {   // not unrolled: keeps the register footprint small
@@ -284,6 +312,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         // C2: inverse stage 3 (radix R3 on contiguous runs), one butterfly per thread
         ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
             const int col = t / C::NB3, q = t % C::NB3;
+            if constexpr (SLICED) { if (col < cur_lo || col >= cur_hi) return; }
             c32* p = lds + col * LP + q * R3;
             c32 v[R3];
             static_for<0, R3 / 2>([&](auto h_) {
@@ -304,17 +333,19 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
 
         FC_COLS_STAMP(2);
         if constexpr (PLAND && FC_COLS_SPLIT_GATHER) ctx.phase_nosync([&](int t, State& st) {
-            if (next < g.ntiles) issue_gather(t, st, next, IC<2>{});
+            if (next < n_total) issue_gather(t, st, next, IC<2>{}, nxt_lo, nxt_hi);
         });
         // C3: inverse stage 2 (radix R2, sub-length R3)
         ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, [[maybe_unused]] State& st) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 if constexpr (PLAND && FC_COLS_SPLIT_GATHER == 2 && r == C::RND2 - 1) {   // last third of the gather: ahead of the last round
-                    if (next < g.ntiles) issue_gather(t, st, next, IC<3>{});
+                    if (next < n_total) issue_gather(t, st, next, IC<3>{}, nxt_lo, nxt_hi);
                 }
                 const int idx = t + NT * r;
-                if (idx < C::NB2 * T) {
+                bool mine2 = idx < C::NB2 * T;
+                if constexpr (SLICED) mine2 = mine2 && idx / C::NB2 >= cur_lo && idx / C::NB2 < cur_hi;
+                if (mine2) {
                     const int col = idx / C::NB2, u = idx % C::NB2;
                     const int c1 = u / R3, b = u % R3;
                     c32* p = lds + col * LP + c1 * m1 + b;
@@ -347,7 +378,9 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             FC_NOUNROLL
             for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the prefetched tile stays in registers
                 const int idx = t + NT * r;
-                if (idx < C::NB1 * T) {
+                bool mine1 = idx < C::NB1 * T;
+                if constexpr (SLICED) mine1 = mine1 && idx / C::NB1 >= cur_lo && idx / C::NB1 < cur_hi;
+                if (mine1) {
                     const int col = idx / C::NB1, j = idx % C::NB1;
                     const c32* p = lds + col * LP + j;
                     c32 pw[R1];
@@ -371,7 +404,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
 
         FC_COLS_STAMP(5);
         // C5: the prefetched tile lands in LDS
-        if (next < g.ntiles) ctx.phase([&](int t, State& st) { land_gather(t, st); });
+        if (next < n_total) ctx.phase([&](int t, State& st) { land_gather(t, st, nxt_lo, nxt_hi); });
         FC_COLS_STAMP(6);
     }
 }

@@ -224,6 +224,29 @@ inline bool fast_cols_dispatch(int M, int T, Runner&& run) {
     return false;
 }
 
+// Sliced tail round of the output kernel (fast_cols.hpp, SLICED): for the small transforms (M <= 1056: the launches of
+// small problems are a handful of rounds of tiles) a last, partial round of `rem` tiles on `want` persistent workgroups is
+// cut into S = 2^k column slices per tile, S <= want / rem and at least 2 columns per slice.  Fills in the tail fields
+// of `a` (and shrinks a.ntiles to the full rounds) and returns the grid to launch; false: launch unsliced.
+constexpr int FC_SLICE_MAX_M = 1056;
+inline bool fast_cols_slice_plan(int M, int T, int want, FastColsArgs& a, int& grid) {
+    a.tail_first = a.tail_tiles = a.slice_shift = 0;
+    if (!a.y_tiled || M > FC_SLICE_MAX_M || want < 2 || a.ntiles <= 0) return false;
+    const int full_rounds = a.ntiles / want, rem = a.ntiles - full_rounds * want;
+    // (launches of less than one round stay whole: cfg1's 18 tiles as 144 two-column slices took 24.6 instead of 22.3 us
+    //  per step -- every slice pays the tile's whole phase latency)
+    if (rem == 0 || full_rounds == 0) return false;
+    int shift = 0;
+    while ((2 << shift) * rem <= want && (T >> (shift + 1)) >= 2) shift++;
+    if (shift == 0) return false;
+    a.tail_first = full_rounds * want;
+    a.tail_tiles = rem;
+    a.slice_shift = shift;
+    a.ntiles = full_rounds * want;
+    grid = want;
+    return true;
+}
+
 struct FastColsTables {
     Plan1D plan;                   // radices (R1, R2, R3)
     std::vector<c32> tw1, tw2;

@@ -121,10 +121,22 @@ struct EmuFastCols {
     int nwg;
     template <class Cfg>
     void go() {
-        for (int wg = 0; wg < nwg; wg++) {
+        FastColsArgs b = a;
+        int sgrid = 0;
+        // the emulator uses 8 "persistent workgroups" where the product's launcher would slice the tail round, so that the
+        // sliced body runs on the CPU tier too (e.g. 18 tiles = 2 full rounds of 8 + 2 tiles in 4 slices each)
+        const bool sliced = (Cfg::M <= FC_SLICE_MAX_M) && fast_cols_slice_plan(Cfg::M, Cfg::T, 8, b, sgrid);
+        const int loops = sliced ? 8 : nwg;
+        for (int wg = 0; wg < loops; wg++) {
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
             if (a.y_tiled) {
                 HostPhaseCtx<ColPairState<Cfg>> pctx(Cfg::NT);
+                if constexpr (Cfg::M <= FC_SLICE_MAX_M) {
+                    if (sliced) {     // the tail round in column slices (fast_cols_slice_plan filled `b`)
+                        if (wg < sgrid) fast_cols_body<Cfg, true, true>(pctx, lds, b, wg, sgrid);
+                        continue;
+                    }
+                }
                 fast_cols_body<Cfg, true>(pctx, lds, a, wg, nwg);
                 continue;
             }
