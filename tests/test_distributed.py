@@ -148,11 +148,12 @@ def test_streamed_convolver_remembers_the_buffer_of_the_last_image():
         assert c.n_run == n_img * calls
 
 
-def test_world2_gloo_emulator_matches_oracle(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 3])
+def test_world_gloo_emulator_matches_oracle(tmp_path, oracle, world):
     subprocess.run(["make", "-C", os.path.join(util.ROOT, "tests", "emu")], check=True,
                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    case = (40, 36, 2, 7, 5, 5, 3)      # 5 filters -> blocks 3 + 2; 3 images -> 2 + 1
-    ranks = run_world(tmp_path, "emu", case)
+    case = (40, 36, 2, 7, 5, 5, 3)      # 5 filters -> blocks 3 + 2 (2 + 2 + 1 on three ranks); 3 images -> 2 + 1 (1 + 1 + 1)
+    ranks = run_world(tmp_path, "emu", case, world=world)
     check_world(oracle, ranks, case, 1e-5)
 
 
@@ -240,6 +241,16 @@ def test_bench_two_ranks_on_one_gpu_cfg4_full_size():
     assert j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
     assert j["config"]["filters_total"] == 128 and j["config"]["filters_per_gpu"] == 64
     assert "gloo" in j["config"]["backend"]
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_one_gpu_uneven_shards():
+    """four ranks on the one GPU (the box allows six processes on the card), 18 filters -> blocks of 5, 5, 4, 4: the
+    uneven split, the reductions over more than two ranks and the teardown of four children"""
+    j = _bench(["--gpus", "4", "--share-gpu", "--config", "cfg2", "--filters", "18", "--steps", "3", "--warmup", "1", "--check",
+                "--no-cpu-baseline"], timeout=900)
+    assert j["n_gpus"] == 4 and j["check_ok"] and j["config"]["filters_total"] == 18
+    assert j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
 
 
 @pytest.mark.gpu
