@@ -476,6 +476,17 @@ def main():
                 kern_d.copy_(kern_pin, non_blocking=True)     # on the plan's stream, ahead of the step that reads them
                 conv.run([img_d])
 
+        # SURVEY 8(d) words the timing as "hipEvents, median of >= 10 after warm-up": the same K steps once more with an event
+        # recorded on the plan's stream after every step (the headline is the wall-clock mean between two device synchronisations)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        conv.run([img_d] * 2)
+        evs[0].record(stream)
+        conv.run([img_d] * args.steps, on_result=lambda k, _r: evs[k + 1].record(stream))
+        torch.cuda.synchronize(dev)
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+        extras["ms_per_step_event_median"] = med
+        extras["value_event_median"] = nf_total * P / (med * 1e-3) / 1e9
         dt_h2d = timed(steps_h2d, args.steps)
         extras["ms_per_step_incl_kernel_h2d"] = dt_h2d / args.steps * 1e3
         extras["value_incl_kernel_h2d"] = nf_total * P * args.steps / dt_h2d / 1e9
