@@ -150,6 +150,26 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 30; i++) rows_launch(Y1, sr, lds_rows);
     CHECK(hipDeviceSynchronize());
 
+    if (argc > 3) {   // power mode: each kernel alone, back to back for ~5 s, while tools/power_by_kernel.sh samples rocm-smi
+        auto soak = [&](const char* name, auto&& body, double seconds) {
+            const auto t0 = std::chrono::steady_clock::now();
+            long n = 0;
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+                for (int i = 0; i < 20; i++) body();
+                CHECK(hipDeviceSynchronize());
+                n += 20;
+            }
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+            printf("%-40s %9.1f us per launch  %6.2f us per map  (%ld launches)\n", name, us, us / maps, n);
+        };
+        printf("PHASE rows\n");
+        soak("rows alone, back to back", [&] { rows_launch(Y1, sr, lds_rows); }, 6.0);
+        printf("PHASE cols8\n");
+        soak("cols8 alone, back to back", [&] { cols_launch(k_c8, 8, 768, lds_c8, Y0, num_cus, sc); }, 6.0);
+        printf("PHASE pair\n");
+        soak("rows then cols8 (the product's step)", [&] { rows_launch(Y1, sr, lds_rows); CHECK(hipStreamSynchronize(sr)); cols_launch(k_c8, 8, 768, lds_c8, Y0, num_cus, sc); CHECK(hipStreamSynchronize(sc)); }, 6.0);
+        return 0;
+    }
     const double t_rows = wall([&] { rows_launch(Y1, sr, lds_rows); });
     report("rows alone (4 workgroups per CU)", t_rows);
     const double t_rows2 = wall([&] { rows_launch(Y1, sr, 78 * 1024); });
