@@ -27,6 +27,12 @@ against the map buffer and keeps the fastest (plan option tune_placement, DESIGN
 steps are followed by more untimed steps where they are shorter than the ~40 ms the GPU's clocks
 need to settle after an idle gap (config.clock_warm_steps).  The timed region is exactly K steps.
 
+Order of a run (round 4): set-up -> `cpu_baseline` (CPU only, rank 0 at N = 1) -> W warm-up steps + >= 1 s of settled
+load (`--settle-s`) -> the K timed steps -> checks -> untimed extra passes (`host_output`: the MEX-faithful host-in /
+host-out entry, one-shot and reused plan; `multi_feature`: F > 1, the reference's sumAlongFeatures case).  The timed
+step contains the upload of the step's kernels from pinned host memory (double-buffered on an upload
+stream: multi_gpu.HipPlanEngine); `value_kernels_resident` is the same K steps with the kernels kept in HBM.
+
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
 kernel, algorithmic bytes / its HIP-event time over the launches of the timed region itself), `cpu_baseline` (the CPU oracle timed on this
 host on a bounded sample, rank 0 at N = 1 only) and `check_max_rel_err` (every map's checksum on
@@ -61,7 +67,8 @@ CONFIGS = {
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 CHECK_TOL_ORACLE = 1e-4   # north_star parity bar (max|out - ref| / max|ref| per map)
 CHECK_TOL_CHECKSUM = 1e-5  # sum(map) vs sum(image) * sum(kernel), relative
-CLOCK_WARM_S = 0.08       # untimed load before the timed region (the clock ramp after idle is ~40 ms)
+CLOCK_WARM_S = 1.0        # untimed load before the timed region (--settle-s): the clock ramp after idle is ~40 ms, and a sampler
+                          # of GPU utilisation outside this process needs about a second of continuous load to see the run
 
 
 def ceil16(n):
@@ -179,6 +186,199 @@ def cpu_baseline(cfg, sample_filters):
     return res, ref
 
 
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def host_output_figures(fc, util, np, torch, dev, cases=(("cfg2", 16), ("cfg3", 64))):
+    """The reference's ONLY mode: host arrays in, host arrays out (src/cudaConvolutionFFT.cu:146-148,221-222,284-286),
+    PCIe-inclusive -- never `value`.  Per case: the literal one-shot entry (fftconv_convolution_fft: first call = plan
+    built, later calls = plan from the cache) and the same work through a plan the caller keeps (set_image + convolve),
+    into output arrays whose pages are resident and into fresh, never-touched ones (what mxCreateNumericArray hands out)."""
+    res = {}
+    # what the link gives: device -> pinned host, 1 GiB
+    try:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty(1 << 28, dtype=torch.float32).pin_memory()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        res["pcie_d2h_pinned_gbps"] = 3 * src.numel() * 4 / (time.perf_counter() - t0) / 1e9
+        del src, dst
+    except Exception as e:   # optional
+        res["pcie_d2h_pinned_gbps"] = None
+        res["pcie_error"] = str(e)
+    res["pcie_spec_gbps"] = 63.0      # MI355X_MICROARCH.md: PCIe Gen5 x16
+    fc.cache_clear()
+    for cfg, n in cases:
+        H, W, F, kh, kw, _nf, seed = CONFIGS[cfg]
+        img, ks = util.synth(seed, H, W, F, kh, kw, n)
+        fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+        P = fh * fw
+        mk = lambda: [np.empty((fh, fw), dtype=np.float32, order="F") for _ in range(n)]
+        outs = mk()
+        for o in outs:
+            o.fill(0.0)            # pages resident
+        r = {"maps": n, "map_mb": P * 4 / 1e6}
+
+        def timed(fn, reps):
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return ts
+
+        first = timed(lambda: fc.cudaConvolutionFFT(img, kh, kw, ks, out=outs), 1)[0]
+        r["one_shot_first_call_ms"] = first                      # builds the plan (tables, scratch, copy threads)
+        r["one_shot_first_call_parts"] = fc.last_call_timing()
+        ts = timed(lambda: fc.cudaConvolutionFFT(img, kh, kw, ks, out=outs), 5)
+        r["one_shot_ms"] = _median(ts)                           # plan from the cache
+        r["one_shot_parts"] = fc.last_call_timing()
+        ts = timed(lambda: fc.cudaConvolutionFFT(img, kh, kw, ks), 3)
+        r["one_shot_fresh_outputs_ms"] = _median(ts)             # + first touch of every output page
+        with fc.Plan(H, W, F, kh, kw) as p:
+            def reused():
+                p.set_image(img)
+                p.convolve(ks, out=outs)
+            reused()
+            r["reused_plan_ms"] = _median(timed(reused, 5))
+        fc.cache_configure(0)                                    # the reference's own behaviour: everything built and torn down per call
+        r["one_shot_no_cache_ms"] = _median(timed(lambda: fc.cudaConvolutionFFT(img, kh, kw, ks, out=outs), 3))
+        fc.cache_configure(4)
+        r["one_shot_over_reused"] = r["one_shot_ms"] / r["reused_plan_ms"]
+        r["one_shot_gpx_per_s"] = n * P / (r["one_shot_ms"] * 1e-3) / 1e9
+        r["reused_plan_gpx_per_s"] = n * P / (r["reused_plan_ms"] * 1e-3) / 1e9
+        r["one_shot_maps_gbps"] = n * P * 4 / (r["one_shot_ms"] * 1e-3) / 1e9
+        r["reused_plan_maps_gbps"] = n * P * 4 / (r["reused_plan_ms"] * 1e-3) / 1e9
+        res[cfg + ("/%d maps" % n if n != CONFIGS[cfg][5] else "")] = r
+        del outs
+        fc.cache_clear()
+    return res
+
+
+def multi_feature_figures(fc, util, np, torch, dev, steps, cases=(("cfg3f4", 4096, 4096, 4, 127, 64), ("cfg3f5 (the demo's F = 5)", 4096, 4096, 5, 127, 32))):
+    """F > 1 -- the only case the reference's gateway accepts (src/cudaConvolutionFFT.cu:51-54,210-211; sumAlongFeatures,
+    src/cudaConvFFTData.cuh:70-92): device-resident steps like the headline's, per-kernel times from HIP events, and
+    SURVEY 8(d)'s algorithmic bytes at F: 4 K^2 F (kernels) + 8 C F (image spectrum) + 16 C (intermediate round trip)
+    + 4 P (map)."""
+    res = {}
+    for name, H, W, F, k, n in cases:
+        rng = np.random.default_rng(4242 + F)
+        img = torch.from_numpy(rng.random((F, W, H), dtype=np.float32)).to(dev)
+        ker = torch.from_numpy(rng.random((n, F, k, k), dtype=np.float32)).to(dev)
+        with fc.Plan(H, W, F, k, k, gpuId=dev.index or 0, stream=torch.cuda.current_stream(dev).cuda_stream) as p:
+            i = p.info
+            P = i.fft_h * i.fft_w
+            C = i.fft_w * (i.fft_h // 2 + 1)
+            out = torch.empty((n, i.fft_w, i.fft_h), dtype=torch.float32, device=dev)
+
+            def step():
+                p.set_image_device(img.data_ptr())
+                p.convolve_packed_device(n, ker.data_ptr(), k, k, out.data_ptr())
+
+            step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize(dev)
+            est = time.perf_counter() - t0
+            for _ in range(max(2, min(50, int(0.3 / max(est, 1e-4))))):      # settle the clocks
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / steps
+            p.set_option("profile", 1)
+            p.profile(reset=True)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(dev)
+            prof = p.profile(reset=True)
+            p.set_option("profile", 0)
+            # the sum over a whole map is sum_f sum(image_f) * sum(kernel_f)
+            s_img = img.sum(dim=(1, 2), dtype=torch.float64)
+            want = (ker.sum(dim=(2, 3), dtype=torch.float64) * s_img[None, :]).sum(dim=1)
+            got = out.sum(dim=(1, 2), dtype=torch.float64)
+            err = float(((got - want).abs() / want.abs()).max().item())
+            b_alg = 4 * k * k * F + 8 * C * F + 16 * C + 4 * P
+            per_map = {kk: prof[kk]["ms"] / max(1, prof[kk]["units"]) * 1e3 for kk in ("spectral_rows", "cols_c2r")}
+            res[name] = {"workload": "%dx%d image, F=%d, %d kernels of %dx%dx%d -> %d maps of %dx%d" % (H, W, F, n, k, k, F, n, i.fft_h, i.fft_w),
+                         "ms_per_step": dt * 1e3, "value": n * P / dt / 1e9, "unit": "Gpixel-filters/s",
+                         "gpixel_features_per_s": n * P * F / dt / 1e9,
+                         "algorithmic_bytes_per_map": b_alg, "hbm_algorithmic_gbps": b_alg * n / dt / 1e9,
+                         "hbm_frac_of_peak": b_alg * n / dt / 1e9 / HBM_PEAK_GBPS,
+                         "us_per_map": {"spectral_rows": per_map["spectral_rows"], "cols_c2r": per_map["cols_c2r"], "step": dt / n * 1e6},
+                         "rows_kernel_gbps": (4 * k * k * F + 8 * C * F + 8 * C) / (per_map["spectral_rows"] * 1e-6) / 1e9,
+                         "check_checksum_max_rel_err": err}
+        del img, ker, out
+    return res
+
+
+def library_sha256(fc):
+    import hashlib
+    try:
+        return hashlib.sha256(open(fc.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def rank_identity(torch, dev):
+    """what proves that N ranks ran on N distinct devices: host, PCI bus id, device name, UUID where the runtime has one"""
+    import socket
+    props = torch.cuda.get_device_properties(dev)
+    bus = None
+    try:   # hipDeviceGetPCIBusId through the HIP runtime torch has loaded
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev.index or 0)) == 0:
+            bus = buf.value.decode()
+    except Exception:
+        bus = None
+    uuid = getattr(props, "uuid", None)
+    return {"host": socket.gethostname(), "pci_bus_id": bus, "uuid": str(uuid) if uuid is not None else None,
+            "name": props.name, "device_index": int(dev.index or 0), "pid": os.getpid()}
+
+
+def numa_prefer_gpu_node(pci_bus_id):
+    """Makes the calling thread PREFER the NUMA node the GPU hangs off for the allocations that follow (set_mempolicy
+    MPOL_PREFERRED: the pinned images are placed when torch touches / pins them).  Returns what happened, for the JSON."""
+    info = {"gpu_numa_node": None, "policy": "default"}
+    try:
+        info["gpu_numa_node"] = int(open("/sys/bus/pci/devices/%s/numa_node" % str(pci_bus_id).lower()).read())
+    except Exception:
+        return info
+    node = info["gpu_numa_node"]
+    if node < 0:
+        return info          # the host does not say (one node, or a virtual machine)
+    try:
+        import ctypes
+        libc = ctypes.CDLL(None, use_errno=True)
+        mask = (ctypes.c_ulong * 16)()
+        mask[node // 64] = 1 << (node % 64)
+        rc = libc.syscall(238, 1, mask, 16 * 64 + 1)          # x86-64: set_mempolicy(MPOL_PREFERRED, mask, maxnode)
+        info["policy"] = ("preferred node %d" % node) if rc == 0 else ("default (set_mempolicy: errno %d)" % ctypes.get_errno())
+    except Exception as e:
+        info["policy"] = "default (%s)" % e
+    return info
+
+
+def numa_restore(info):
+    if info and info.get("policy", "").startswith("preferred"):
+        try:
+            import ctypes
+            ctypes.CDLL(None).syscall(238, 0, None, 0)          # MPOL_DEFAULT
+        except Exception:
+            pass
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` by hand: start the N ranks (fresh processes, before anything in
     this one touches the GPU) and exit with their status; rank 0 prints the JSON line."""
@@ -252,6 +452,16 @@ def main():
                     help="torch.distributed backend (default: nccl = RCCL over xGMI; gloo with --share-gpu)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra passes (kernel-upload-inclusive steps, default-options plan): A/B runs")
+    ap.add_argument("--exact-window", action="store_true",
+                    help="plans transform the ceil16 window itself (fftconv_plan_options.exact_window): A/B of the window's own "
+                         "specialised kernels (1088, 4160) against the next convenient length + crop")
+    ap.add_argument("--settle-s", type=float, default=CLOCK_WARM_S,
+                    help="seconds of untimed load (warm-up steps included) in front of the timed region")
+    ap.add_argument("--kernels-resident", action="store_true",
+                    help="keep the kernels in HBM instead of uploading them from pinned host memory inside every step (A/B; the "
+                         "default run reports this figure as value_kernels_resident)")
+    ap.add_argument("--no-host-output", action="store_true", help="skip the host-in / host-out figures (host_output)")
+    ap.add_argument("--no-multi-feature", action="store_true", help="skip the F > 1 figures (multi_feature)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -288,6 +498,18 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # who takes part: every rank's host, PCI bus id and device name, gathered on all ranks -- N ranks must sit on N
+    # distinct devices unless this is the one-GPU rehearsal
+    ident = rank_identity(torch, dev)
+    idents = [ident]
+    if use_dist and world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    distinct_devices = len(set((i["host"], i["pci_bus_id"] or i["uuid"] or i["device_index"]) for i in idents))
+    if world > 1 and distinct_devices != world and not args.share_gpu:
+        raise SystemExit("bench.py: %d ranks on %d distinct devices (%s); --share-gpu is the one-GPU rehearsal"
+                         % (world, distinct_devices, [(i["host"], i["pci_bus_id"]) for i in idents]))
+
     fc = util.load_package()
     import importlib
     mg = importlib.import_module(fc.__name__ + ".multi_gpu")
@@ -314,7 +536,8 @@ def main():
     kern_d = torch.from_numpy(kern_h).to(dev)
 
     stream = torch.cuda.current_stream(dev)
-    plan = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream)
+    plan_opts = {"exact_window": 1} if args.exact_window else None
+    plan = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream, options=plan_opts)
     info = plan.info
     P = info.fft_h * info.fft_w
     if args.batch_maps:
@@ -330,23 +553,35 @@ def main():
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
     # the next image's H2D copy (streamed mode)
     overlap = streamed or ((use_dist or args.overlap) and not args.no_overlap)
-    engine = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap)
+    # the kernels' column pass rides in the image transform's launch where that transform follows on the plan's own stream
+    defer_prepare = streamed or not overlap
+    # the step's kernels are uploaded inside the step, from pinned host memory, double-buffered on an upload stream
+    upload_kernels = not args.kernels_resident and not args.graph and nf > 0
+    kern_pin = torch.from_numpy(kern_h).pin_memory() if upload_kernels else None
+    engine = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap,
+                              defer_prepare=defer_prepare, kernels_host=kern_pin)
     out = engine.out
 
     if streamed:
         # images of this rank in pinned host memory (seeded per global image index)
+        # ... allocated on the NUMA node of this rank's GPU where the host says which one that is: eight ranks streaming
+        # from one host's DRAM is the case that decides cfg5's scaling (pinned H2D drops to ~17 GB/s once the images fall
+        # out of the host caches; a remote node halves that again)
+        numa = numa_prefer_gpu_node(ident["pci_bus_id"])
         imgs_h = []
         for i in range(n_img):
             a = np.random.default_rng(1234 + seed + 1000 * (img_first + i)).random((F, W, H), dtype=np.float32)
             imgs_h.append(torch.from_numpy(a).pin_memory())
-        conv = mg.ImageStreamedConvolver(engine, nf)
+        numa_restore(numa)
+        conv = mg.ImageStreamedConvolver(engine, nf, time_uploads=True)
 
         def run_steps(k):
             conv.run(imgs_h * k)      # k steps = the batch streamed k times back to back (the first H2D copy of a
                                       # step rides behind the last image of the step before)
     else:
         conv = mg.FilterShardedConvolver(engine, dist if use_dist else None, rank, world, nf_total, src=0,
-                                         depth=2 if overlap else 1, always_collective=args.force_collective)
+                                         depth=2 if overlap else 1, always_collective=args.force_collective,
+                                         time_broadcast=("event" if backend == "nccl" else "wall") if use_dist else None)
 
         def run_steps(k):
             conv.run([img_d] * k)
@@ -356,6 +591,11 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    # the CPU baseline FIRST (CPU only, ~15 s): the GPU phases then run in one piece at the end of the process
+    cpu = cpu_ref = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, cpu_ref = cpu_baseline(cfg, args.cpu_sample)
 
     run_steps(args.warmup)
     barrier()
@@ -372,8 +612,8 @@ def main():
             te = torch.tensor([est], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             est = float(te.item())
-        if (args.warmup + 1) * est < CLOCK_WARM_S:
-            clock_warm_steps = min(3000, int(CLOCK_WARM_S / max(est, 1e-6)) + 1)
+        if (args.warmup + 1) * est < args.settle_s:
+            clock_warm_steps = min(60000, int(args.settle_s / max(est, 1e-6)) + 1)
             for c0 in range(0, clock_warm_steps, 64):     # in short bursts: never a deep queue behind the host
                 run_steps(min(64, clock_warm_steps - c0))
                 torch.cuda.synchronize(dev)
@@ -409,23 +649,43 @@ def main():
         plan.set_option("profile_kinds", (1 << 1) | (1 << 2))   # indices of fftconv_profile: spectral_rows, cols_c2r
         plan.set_option("profile", 1)
         plan.profile(reset=True)
+    if not streamed:
+        conv.broadcast_ms(reset=True)
+    else:
+        conv.upload_ms(reset=True)
+    uploads0 = engine.uploads
     t0 = time.perf_counter()
     if graph is not None:
         for _ in range(args.steps):
             graph.replay()
     else:
         run_steps(args.steps)
+    torch.cuda.synchronize(dev)
+    dt_rank = time.perf_counter() - t0          # this rank's own time (the headline is the max over ranks, behind the barrier)
     barrier()
     dt = time.perf_counter() - t0
+    kernel_uploads_timed = engine.uploads - uploads0
+    bcast_ms = conv.broadcast_ms() if not streamed else []
+    upload_ms = conv.upload_ms() if streamed else []
     live = None
     if live_profile:
         live = plan.profile(reset=True)
         plan.set_option("profile", 0)
         plan.set_option("profile_kinds", 0)
+    per_rank = None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # per rank: its own K steps, its broadcasts (prologue), its H2D rate -- a sub-6x result can then be attributed
+        img_bytes = 4.0 * F * W * H
+        mine = {"rank": rank, "ms_per_step": dt_rank / args.steps * 1e3, "filters": nf,
+                "broadcast_ms_mean": (sum(bcast_ms) / len(bcast_ms)) if bcast_ms else None,
+                "broadcast_ms_max": max(bcast_ms) if bcast_ms else None, "broadcasts": len(bcast_ms),
+                "h2d_gbps": (img_bytes * len(upload_ms) / (sum(upload_ms) * 1e-3) / 1e9) if upload_ms and sum(upload_ms) > 0 else None,
+                "images": n_img if streamed else None, "pinned_images_numa": numa if streamed else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # self-check of what the timed steps left in `out` (every map of this rank, on the device):
     # the sum over the whole window of a linear convolution is sum(image) * sum(kernel)
@@ -461,8 +721,6 @@ def main():
     #  * the same K steps on a second plan with DEFAULT options (no placement tuning) writing into the same maps.
     extras = {}
     if world == 1 and not use_dist and not streamed and graph is None and not args.no_extras and nf:
-        kern_pin = torch.from_numpy(kern_h).pin_memory()
-
         def timed(fn, k):
             fn(max(1, min(k, 3)))
             torch.cuda.synchronize(dev)
@@ -471,11 +729,6 @@ def main():
             torch.cuda.synchronize(dev)
             return time.perf_counter() - t1
 
-        def steps_h2d(k):
-            for _ in range(k):
-                kern_d.copy_(kern_pin, non_blocking=True)     # on the plan's stream, ahead of the step that reads them
-                conv.run([img_d])
-
         # SURVEY 8(d) words the timing as "hipEvents, median of >= 10 after warm-up": the same K steps once more with an event
         # recorded on the plan's stream after every step (the headline is the wall-clock mean between two device synchronisations)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -483,18 +736,23 @@ def main():
         evs[0].record(stream)
         conv.run([img_d] * args.steps, on_result=lambda k, _r: evs[k + 1].record(stream))
         torch.cuda.synchronize(dev)
-        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-        med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+        med = _median([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)])
         extras["ms_per_step_event_median"] = med
         extras["value_event_median"] = nf_total * P / (med * 1e-3) / 1e9
-        dt_h2d = timed(steps_h2d, args.steps)
-        extras["ms_per_step_incl_kernel_h2d"] = dt_h2d / args.steps * 1e3
-        extras["value_incl_kernel_h2d"] = nf_total * P * args.steps / dt_h2d / 1e9
+        if upload_kernels:
+            # the same K steps with the kernels kept in HBM (the bench contract's "inputs already resident"; rounds 1-3's headline)
+            eng_r = mg.HipPlanEngine(torch, fc, plan, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap, out=out,
+                                     defer_prepare=defer_prepare)
+            conv_r = mg.FilterShardedConvolver(eng_r, None, rank, world, nf_total, src=0, depth=2 if overlap else 1)
+            dt_r = timed(lambda k: conv_r.run([img_d] * k), args.steps)
+            extras["ms_per_step_kernels_resident"] = dt_r / args.steps * 1e3
+            extras["value_kernels_resident"] = nf_total * P * args.steps / dt_r / 1e9
         if tune_k > 1:
-            plan2 = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream)
+            plan2 = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream, options=plan_opts)
             if args.batch_maps:
                 plan2.set_option("batch_maps", args.batch_maps)
-            eng2 = mg.HipPlanEngine(torch, fc, plan2, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap, out=out)
+            eng2 = mg.HipPlanEngine(torch, fc, plan2, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap, out=out,
+                                    defer_prepare=defer_prepare, kernels_host=kern_pin)
             conv2 = mg.FilterShardedConvolver(eng2, None, rank, world, nf_total, src=0, depth=2 if overlap else 1)
             conv2.run([img_d] * max(2, args.warmup))
             dt2 = timed(lambda k: conv2.run([img_d] * k), args.steps)
@@ -514,12 +772,9 @@ def main():
         ref = orc.conv_fft(chk_img_h, kh, kw, ks)
         for j, r in zip(idx, ref):
             errs.append(util.rel_err(out[j].cpu().numpy().T, r))   # [w][h] -> h x w
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, ref = cpu_baseline(cfg, args.cpu_sample)
-        if not streamed:        # the oracle's maps of the first filters double as a check
-            for j, r in enumerate(ref[:nf]):
-                errs.append(util.rel_err(out[j].cpu().numpy().T, r))
+    if cpu_ref is not None and not streamed:        # the oracle's maps of the first filters (CPU baseline sample) double as a check
+        for j, r in enumerate(cpu_ref[:nf]):
+            errs.append(util.rel_err(out[j].cpu().numpy().T, r))
     oracle_err = max(errs) if errs else None
     if use_dist:
         tt = torch.tensor([check["checksum_max_rel_err"], oracle_err if oracle_err is not None else -1.0],
@@ -551,6 +806,7 @@ def main():
         dom = max(per, key=lambda k: per[k]["avg_ms"] / per[k]["units_per_launch"]) if per else None
         traffic = None
         traffic_src = None
+        traffic_lib = None
         physical_per_map = None      # PMC bytes of both hot kernels per map (FETCH x 2 + WRITE, profiles/traffic.json)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if dom and os.path.exists(tpath):
@@ -559,6 +815,7 @@ def main():
                 per_map = tj.get(cfg, {}).get(dom)
                 traffic = per_map * per[dom]["units_per_launch"] if per_map else None
                 traffic_src = tj.get("_source")
+                traffic_lib = tj.get("_library_sha256")
                 if all(tj.get(cfg, {}).get(k) for k in ("spectral_rows", "cols_c2r")):
                     physical_per_map = tj[cfg]["spectral_rows"] + tj[cfg]["cols_c2r"]
             except Exception:
@@ -586,7 +843,10 @@ def main():
                        "transform": [info.transform_h, info.transform_w],
                        "filters_total": nf_total,
                        "filters_per_gpu": nf if streamed else -(-nf_total // world),
-                       "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps,
+                       "kernels": ("uploaded from pinned host memory inside every step (SURVEY 8(d)): %d uploads in the %d timed steps, "
+                                   "double-buffered on an upload stream" % (kernel_uploads_timed, args.steps)) if upload_kernels
+                                  else "resident in HBM",
+                       "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps, "settle_s": args.settle_s,
                        "tune_placement": {"candidates": plan.get_option("tuned_candidates"), "kept": plan.get_option("tuned_best")} if tune_k > 1 else None,
                        "images_per_step": args.images if streamed else 1,
                        "parallelism": ("images x%d, streamed H2D" % world) if streamed else
@@ -607,6 +867,9 @@ def main():
             result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per[dom]["gbps"], "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s", "frac": per[dom]["gbps"] / HBM_PEAK_GBPS, "traffic": traffic,
                                   "traffic_source": traffic_src,
+                                  # the PMC passes are separate runs: which binary they measured, and whether it is the one running now
+                                  "traffic_measured_at": traffic_lib, "library_sha256": library_sha256(fc),
+                                  "traffic_is_of_this_binary": (traffic_lib == library_sha256(fc)) if traffic_lib else None,
                                   "algorithmic_bytes_per_launch": ab[dom] * per[dom]["units_per_launch"],
                                   "avg_launch_ms": per[dom]["avg_ms"]}
         result.update(extras)
@@ -625,12 +888,31 @@ def main():
                     pass
         if use_dist:
             result["config"]["backend"] = backend + (" (all ranks on cuda:0: rehearsal)" if args.share_gpu else "")
+            result["ranks"] = idents
+            result["distinct_devices"] = distinct_devices
+            result["per_rank"] = per_rank
+            if streamed:
+                result["config"]["pinned_images_numa"] = numa
         if cpu is not None:
             result["cpu_baseline"] = cpu
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     plan.destroy()
+    if rank == 0 and world == 1 and not use_dist and not args.no_extras and result is not None:
+        # untimed for the headline: the MEX-faithful surface (host in / host out) and the F > 1 case, from THIS binary
+        del engine, conv, out
+        torch.cuda.empty_cache()
+        if not args.no_host_output:
+            try:
+                result["host_output"] = host_output_figures(fc, util, np, torch, dev)
+            except Exception as e:   # reported, never fatal for the headline
+                result["host_output"] = {"error": repr(e)}
+        if not args.no_multi_feature:
+            try:
+                result["multi_feature"] = multi_feature_figures(fc, util, np, torch, dev, max(3, min(args.steps, 10)))
+            except Exception as e:
+                result["multi_feature"] = {"error": repr(e)}
     if rank == 0:
         # RCCL prints a version banner through C stdio, which would otherwise be flushed after
         # Python's output at exit: flush it first so that the JSON line is the LAST line of stdout

@@ -56,10 +56,21 @@ class PlanInfo(ctypes.Structure):
 class PlanOptions(ctypes.Structure):
     """fftconv_plan_options (include/fftconv.h): choices fixed at plan creation."""
     _fields_ = [("struct_size", ctypes.c_size_t), ("kernel_path", ctypes.c_int), ("rows_group", ctypes.c_int),
-                ("max_transform", ctypes.c_int), ("exact_window", ctypes.c_int), ("blockwise", ctypes.c_int)]
+                ("max_transform", ctypes.c_int), ("exact_window", ctypes.c_int), ("blockwise", ctypes.c_int),
+                ("verbose", ctypes.c_int)]
 
-    def __init__(self, kernel_path=0, rows_group=0, max_transform=0, exact_window=0, blockwise=0):
-        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform), int(exact_window), int(blockwise))
+    def __init__(self, kernel_path=0, rows_group=0, max_transform=0, exact_window=0, blockwise=0, verbose=0):
+        super().__init__(ctypes.sizeof(PlanOptions), int(kernel_path), int(rows_group), int(max_transform), int(exact_window), int(blockwise),
+                         int(verbose))
+
+
+class CallTiming(ctypes.Structure):
+    """fftconv_call_timing: where the time of the last one-shot call of this thread went (ms)."""
+    _fields_ = [("plan_ms", ctypes.c_double), ("image_ms", ctypes.c_double), ("convolve_ms", ctypes.c_double),
+                ("release_ms", ctypes.c_double), ("total_ms", ctypes.c_double), ("cache_hit", ctypes.c_int)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 def _options_ptr(options):
@@ -84,7 +95,9 @@ class Profile(ctypes.Structure):
 # every symbol include/fftconv.h declares
 EXPORTED_SYMBOLS = (
     "fftconv_fft_size16", "fftconv_fft_size_pow2", "fftconv_last_error", "fftconv_version", "fftconv_device_count",
-    "fftconv_convolution_fft", "fftconv_convolution_fft_ex", "fftconv_plan_create", "fftconv_plan_create_ex",
+    "fftconv_convolution_fft", "fftconv_convolution_fft_ex",
+    "fftconv_cache_configure", "fftconv_cache_clear", "fftconv_cache_stats", "fftconv_last_call_timing",
+    "fftconv_plan_create", "fftconv_plan_create_ex",
     "fftconv_plan_is_live", "fftconv_plan_destroy", "fftconv_plan_get_info",
     "fftconv_plan_set_image", "fftconv_plan_spectrum", "fftconv_plan_mark_spectrum_valid",
     "fftconv_plan_use_spectrum_buffer", "fftconv_plan_export_spectrum", "fftconv_plan_import_spectrum",
@@ -139,6 +152,11 @@ def load_library():
     lib.fftconv_device_count.argtypes = [pi]
     lib.fftconv_convolution_fft.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, pi, pi]
     lib.fftconv_convolution_fft_ex.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp, pi, pi, vp]
+    lib.fftconv_cache_configure.argtypes = [ci, cs]
+    lib.fftconv_cache_clear.argtypes = []
+    lib.fftconv_cache_stats.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long),
+                                        ctypes.POINTER(cs)]
+    lib.fftconv_last_call_timing.argtypes = [ctypes.POINTER(CallTiming)]
     lib.fftconv_plan_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, vp]
     lib.fftconv_plan_create_ex.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ci, ci, vp, vp]
     lib.fftconv_plan_is_live.argtypes = [vp]
@@ -172,6 +190,10 @@ def load_library():
     lib.fftconv_multi_plan.argtypes = [vp, ci, ctypes.POINTER(vp), pi]
     lib.fftconv_convolution_fft_multi.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, pi, ci, vp, pi, pi]
     _lib = lib
+    # the one-shot entries keep their last few plans (device scratch, host copy threads): released before the
+    # interpreter tears the HIP runtime down (the MEX gateways do the same with mexAtExit)
+    import atexit
+    atexit.register(lib.fftconv_cache_clear)
     return lib
 
 
@@ -194,6 +216,28 @@ def device_count():
     n = ctypes.c_int(0)
     load_library().fftconv_device_count(ctypes.byref(n))
     return n.value
+
+
+def cache_configure(max_plans=4, max_bytes=0):
+    """plan cache of the one-shot entry: plans kept (0 = off), device bytes they may hold (0 = unchanged)"""
+    _check(load_library().fftconv_cache_configure(int(max_plans), int(max_bytes)))
+
+
+def cache_clear():
+    _check(load_library().fftconv_cache_clear())
+
+
+def cache_stats():
+    n, h, m, b = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), ctypes.c_size_t(0)
+    _check(load_library().fftconv_cache_stats(ctypes.byref(n), ctypes.byref(h), ctypes.byref(m), ctypes.byref(b)))
+    return {"plans": n.value, "hits": h.value, "misses": m.value, "device_bytes": b.value}
+
+
+def last_call_timing():
+    """where the time of this thread's last cudaConvolutionFFT call went (dict of ms + cache_hit)"""
+    t = CallTiming()
+    _check(load_library().fftconv_last_call_timing(ctypes.byref(t)))
+    return t.as_dict()
 
 
 def _as_matlab_single(a, what):
@@ -226,10 +270,11 @@ def _thread_size(threads):
     return ctypes.c_void_p(t.ctypes.data), int(t.size), t
 
 
-def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None, gpuId=0, options=None):
+def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None, gpuId=0, options=None, out=None):
     """One-shot convolution, host arrays in / host arrays out (list of FFT_H x FFT_W float32,
     Fortran order).  Mirrors the MEX entry of src/cudaConvolutionFFT.cu.  ``options``: a
-    PlanOptions (or a dict of its fields) for fftconv_convolution_fft_ex."""
+    PlanOptions (or a dict of its fields) for fftconv_convolution_fft_ex; ``out``: optional list of
+    caller buffers (FFT_H x FFT_W float32, Fortran order) to fill instead of fresh arrays."""
     lib = load_library()
     if not isinstance(kernelCell, (list, tuple)):
         raise FFTConvError(-1, "Kernel must be a cell array")  # src/cudaConvolutionFFT.cu:64-65
@@ -238,7 +283,12 @@ def cudaConvolutionFFT(data, maxKernelH, maxKernelW, kernelCell, threadSize=None
     ks, kptr, kh, kw, kf = _kernel_tables(kernelCell)
     n = len(ks)
     fh, fw = fft_size16(H + int(maxKernelH) - 1), fft_size16(W + int(maxKernelW) - 1)
-    outs = [np.empty((fh, fw), dtype=np.float32, order="F") for _ in range(n)]
+    if out is None:
+        outs = [np.empty((fh, fw), dtype=np.float32, order="F") for _ in range(n)]
+    else:
+        outs = list(out)
+        if len(outs) != n or any(o.dtype != np.float32 or o.shape != (fh, fw) or not o.flags.f_contiguous for o in outs):
+            raise FFTConvError(-1, "out must hold one FFT_H x FFT_W float32 Fortran-order buffer per kernel")
     optr = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
     tptr, tn, _keep = _thread_size(threadSize)
     ofh, ofw = ctypes.c_int(0), ctypes.c_int(0)

@@ -16,51 +16,90 @@
 
 namespace fc {
 
-// X(L, R1, R2, R3, NT, RPW, NZ2): see fast_rows.hpp.  NT = 192 threads (3 waves) everywhere;
-// RPW rows per workgroup chosen so that RPW * R1 * R2 = 192 stage-3 butterflies fill the lanes.
-//   4224 = 8 x 24 x 22 (cfg3; cfg4's 4160 window also runs on it): butterflies 528 / 176 / 192
+// planner factors of the two awkward BASELINE windows (see fast_rows_factor): above ~0.5 the planner prefers the next
+// convenient length (1152 / 4224) and crops; exact_window plans use the window's own kernels regardless
+constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
+
+// X(L, R1, R2, R3, NT, RPW, NZ2): see fast_rows.hpp.  NT = 192 threads (3 waves) for rows up to 4224 points;
+// RPW rows per workgroup chosen so that RPW * R1 * R2 (the stage-3 butterflies) fill the lanes.
+//   4224 = 8 x 24 x 22 (cfg3; cfg4's 4160 window can run on it and crop): butterflies 528 / 176 / 192
+//   4160 = 10 x 16 x 26 (round 4: cfg4's window itself -- the reference's own cuFFT size, src/cudaConvolutionFFT.cu:103-110 --
+//          needed by exact_window plans, i.e. the spectrum exchange in the reference's order): 416 / 260 / 160
 //   2112 = 8 x 12 x 22, 2 rows (cfg5):                            528 / 352 / 192
-//   1152 = 8 x 12 x 12, 2 rows (cfg2's 1088 window):              288 / 192 / 192   (round 3: was 6 x 8 x 24 with 4 rows per workgroup --
+//   1152 = 8 x 12 x 12, 2 rows:                                   288 / 192 / 192   (round 3: was 6 x 8 x 24 with 4 rows per workgroup --
 //          160 registers, 3 waves per SIMD, 145 row groups; the lighter radix-12 stage 3 needs about 100 and twice as many,
 //          half as long workgroup steps fill the chip better: cfg2 196 -> 209 Gpx/s, 256 filters 321 -> 335)
+//   1088 = 17 x 4 x 16, 2 rows (round 4: cfg2's window itself):   128 / 544 / 136; kernels up to 64 wide
 //   8448 = 16 x 24 x 22, 2 rows per workgroup of 768 threads (8192-sized images): 528 / 352 / 384 per row.  (Round 3: as
 //          one row per 384-thread workgroup only ONE workgroup was ever resident per CU -- at more than 128 VGPRs the
 //          hardware does not admit a second 6-wave workgroup, profiles/r03a_fused_roles_sq_counters.txt: 5.7 waves per CU;
 //          a 12-wave workgroup is resident whole)
 //   6144 = 16 x 24 x 16, 384 threads (images between 4224 and 6144): 384 / 256 / 384; its F = 1 kernels need <= 128 VGPRs
 //          (4 waves per SIMD), where two 6-wave workgroups do share a CU
+//   5120 = 16 x 20 x 16, 320 threads (round 4): every stage exactly one butterfly per thread: 320 / 256 / 320
+//   3520 = 10 x 16 x 22 (round 4):                                352 / 220 / 160
 //   3072 = 8 x 24 x 16 (images around 2500 - 3000):               384 / 128 / 192
+//   2560 = 8 x 20 x 16 (round 4):                                 320 / 128 / 160
+//   1760 = 10 x 8 x 22, 2 rows (round 4):                         352 / 440 / 160
 //   1536 = 8 x 12 x 16, 2 rows (1280-wide images):                384 / 256 / 192
+//   1344 = 6 x 16 x 14, 2 rows (round 4):                         448 / 168 / 192
 //    768 = 4 x 12 x 16, 4 rows (640 / 720-sized images):          768 / 256 / 192
 //    576 = 4 x 12 x 12, 4 rows (512-sized images):                576 / 192 / 192
 //    288 = 4 x  6 x 12, 8 rows (cfg1):                            576 / 384 / 192
-// Listed with ascending NZ2 per length (the dispatcher takes the first that covers the kernel).
-#define FC_FAST_ROW_CONFIGS(X)      \
+// Round 4's lengths close the gaps of the ladder: a transform is at most ~1.2 x the padded size per dimension instead of
+// 1.45 x (tools/size_sweep.py).  Listed with ascending NZ2 per length (the dispatcher takes the first that covers the
+// kernel).  Three groups, one translation unit each per kernel family (kernels_rows*_g?.hip): build time only.
+#define FC_FAST_ROW_CONFIGS_G0(X)   \
     X(8448, 16, 24, 22, 768, 2, 3)  \
     X(8448, 16, 24, 22, 768, 2, 6)  \
     X(8448, 16, 24, 22, 768, 2, 24) \
     X(6144, 16, 24, 16, 384, 1, 3)  \
     X(6144, 16, 24, 16, 384, 1, 6)  \
     X(6144, 16, 24, 16, 384, 1, 24) \
+    X(5120, 16, 20, 16, 320, 1, 4)  \
+    X(5120, 16, 20, 16, 320, 1, 20)
+#define FC_FAST_ROW_CONFIGS_G1(X)   \
     X(4224, 8, 24, 22, 192, 1, 3)   \
     X(4224, 8, 24, 22, 192, 1, 6)   \
     X(4224, 8, 24, 22, 192, 1, 24)  \
+    X(4160, 10, 16, 26, 192, 1, 3)  \
+    X(4160, 10, 16, 26, 192, 1, 16) \
+    X(3520, 10, 16, 22, 192, 1, 3)  \
+    X(3520, 10, 16, 22, 192, 1, 16) \
     X(3072, 8, 24, 16, 192, 1, 3)   \
     X(3072, 8, 24, 16, 192, 1, 6)   \
     X(3072, 8, 24, 16, 192, 1, 24)  \
+    X(2560, 8, 20, 16, 192, 1, 4)   \
+    X(2560, 8, 20, 16, 192, 1, 20)
+#define FC_FAST_ROW_CONFIGS_G2(X)   \
     X(2112, 8, 12, 22, 192, 2, 3)   \
     X(2112, 8, 12, 22, 192, 2, 12)  \
+    X(1760, 10, 8, 22, 192, 2, 3)   \
+    X(1760, 10, 8, 22, 192, 2, 8)   \
     X(1536, 8, 12, 16, 192, 2, 3)   \
     X(1536, 8, 12, 16, 192, 2, 12)  \
+    X(1344, 6, 16, 14, 192, 2, 3)   \
+    X(1344, 6, 16, 14, 192, 2, 16)  \
     X(1152, 8, 12, 12, 192, 2, 3)   \
     X(1152, 8, 12, 12, 192, 2, 6)   \
     X(1152, 8, 12, 12, 192, 2, 12)  \
+    X(1088, 17, 4, 16, 192, 2, 2)   \
+    X(1088, 17, 4, 16, 192, 2, 4)   \
     X(768, 4, 12, 16, 192, 4, 3)    \
     X(768, 4, 12, 16, 192, 4, 12)   \
     X(576, 4, 12, 12, 192, 4, 3)    \
     X(576, 4, 12, 12, 192, 4, 12)   \
     X(288, 4, 6, 12, 192, 8, 3)     \
     X(288, 4, 6, 12, 192, 8, 6)
+#define FC_FAST_ROW_CONFIGS(X) FC_FAST_ROW_CONFIGS_G0(X) FC_FAST_ROW_CONFIGS_G1(X) FC_FAST_ROW_CONFIGS_G2(X)
+constexpr int FC_ROW_GROUPS = 3;
+// the configurations of group G only
+#define FC_ROW_CONFIGS_OF_GROUP(G, X)                                   \
+    do {                                                                \
+        if constexpr ((G) == 0) { FC_FAST_ROW_CONFIGS_G0(X) }           \
+        else if constexpr ((G) == 1) { FC_FAST_ROW_CONFIGS_G1(X) }      \
+        else { FC_FAST_ROW_CONFIGS_G2(X) }                              \
+    } while (0)
 
 struct FastRowsInfo {
     bool ok = false;
@@ -87,33 +126,54 @@ inline FastRowsInfo fast_rows_lookup(int L, int max_kw) {
 
 inline bool fast_rows_length(int L, int max_kw) { return fast_rows_lookup(L, max_kw < 1 ? 1 : max_kw).ok; }
 
-// Calls run.template go<Cfg, NZ2>() for the first listed configuration of length L whose NZ2
-// covers `nz2_needed` (configurations are listed with ascending NZ2).  false if there is none.
-template <class Runner>
-inline bool fast_rows_dispatch(int L, int nz2_needed, Runner&& run) {
+// Cost per point of a specialised length relative to the planner's generic estimate (planner.hpp: LengthFactor; 0 = no
+// specialised kernel).  0.45 is what the specialised kernels measure against the generic ones; the two BASELINE windows
+// that are awkward to factor carry what their own kernels measure against the next convenient length + crop
+// (profiles/r04*_native_window_ab.txt): 1088 = 2^6 x 17 against 1152, 4160 = 2^6 x 5 x 13 against 4224.
+inline double fast_rows_factor(int L, int max_kw) {
+    if (!fast_rows_length(L, max_kw)) return 0.0;
+    if (L == 1088) return FC_FACTOR_1088;
+    if (L == 4160) return FC_FACTOR_4160;
+    return 0.45;
+}
+
+// Calls run.template go<Cfg, NZ2>() for the first listed configuration of length L (in group G: the translation units
+// of a kernel family instantiate one group each) whose NZ2 covers `nz2_needed` (configurations are listed with
+// ascending NZ2).  false if there is none.
+template <int G, class Runner>
+inline bool fast_rows_dispatch_group(int L, int nz2_needed, Runner&& run) {
 #define FC_X(LL, A, B, C, NTT, RP, NZ)                          \
     if (L == LL && nz2_needed <= NZ) {                          \
         run.template go<RowCfg<LL, A, B, C, NTT, RP>, NZ>();    \
         return true;                                            \
     }
-    FC_FAST_ROW_CONFIGS(FC_X)
+    FC_ROW_CONFIGS_OF_GROUP(G, FC_X);
 #undef FC_X
     return false;
+}
+template <class Runner>
+inline bool fast_rows_dispatch(int L, int nz2_needed, Runner&& run) {
+    return fast_rows_dispatch_group<0>(L, nz2_needed, run) || fast_rows_dispatch_group<1>(L, nz2_needed, run) ||
+           fast_rows_dispatch_group<2>(L, nz2_needed, run);
 }
 
 // Forward image-row kernel (fast_rows_fwd.hpp): one instantiation per length (the first listed
 // configuration of that length; NZ2 does not matter).  run.template go<Cfg>().
-template <class Runner>
-inline bool fast_rows_fwd_dispatch(int L, Runner&& run) {
+template <int G, class Runner>
+inline bool fast_rows_fwd_dispatch_group(int L, Runner&& run) {
     bool done = false;
 #define FC_X(LL, A, B, C, NTT, RP, NZ)                          \
     if (!done && L == LL) {                                     \
         run.template go<RowCfg<LL, A, B, C, NTT, RP>>();        \
         done = true;                                            \
     }
-    FC_FAST_ROW_CONFIGS(FC_X)
+    FC_ROW_CONFIGS_OF_GROUP(G, FC_X);
 #undef FC_X
     return done;
+}
+template <class Runner>
+inline bool fast_rows_fwd_dispatch(int L, Runner&& run) {
+    return fast_rows_fwd_dispatch_group<0>(L, run) || fast_rows_fwd_dispatch_group<1>(L, run) || fast_rows_fwd_dispatch_group<2>(L, run);
 }
 
 // Host tables of a fast row configuration.
@@ -149,7 +209,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   stage butterflies per tile 2112 / 1408 / 768 -> 2.75 / 1.83 / 1.0 rounds of 768 lanes.
 // ---------------------------------------------------------------------------------------
 //   M = 1056 (FFT_H 2112, cfg5): 6 x 8 x 22, 16 columns per tile (full 128-byte lines), 768 threads
-//   M =  576 (transform 1152, cfg2): 6 x 8 x 12, 16 columns, 768 threads
+//   M =  576 (transform 1152): 6 x 8 x 12, 16 columns, 768 threads
 //   M = 4224 (transform 8448, 8192-sized images): 8 x 24 x 22, 4 columns per tile (LDS), 768 threads
 //   M = 3072 (transform 6144): 8 x 24 x 16, 4 columns per tile, 768 threads
 //   M = 1536 / 768 / 384 (transforms 3072 / 1536 / 768): 8 x 12 x 16 (8 columns), 6 x 8 x 16, 4 x 6 x 16
@@ -157,17 +217,37 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   M =  144 (FFT_H 288, cfg1): 4 x 6 x 6, 16 columns, 384 threads
 //   (M = 2112 as 4 columns / 384 threads, two workgroups per CU, was measured much slower: 32-byte
 //   gather pieces, 47.8 vs 36.1 us per map)
-#define FC_FAST_COL_CONFIGS(X)   \
-    X(4224, 8, 24, 22, 4, 768)   \
-    X(3072, 8, 24, 16, 4, 768)   \
-    X(2112, 8, 12, 22, 8, 768)   \
-    X(1536, 8, 12, 16, 8, 768)   \
-    X(1056, 6, 8, 22, 16, 768)   \
-    X(768, 6, 8, 16, 16, 768)    \
-    X(576, 6, 8, 12, 16, 768)    \
-    X(384, 4, 6, 16, 16, 384)    \
-    X(288, 4, 6, 12, 16, 384)    \
+//   Round 4 (one stage-3 butterfly per thread fixes NT = R1 * R2 * T; 640 threads = 10 waves where 768 do not divide):
+//   M = 2080 (FFT_H 4160, cfg4's own window): 8 x 10 x 26, 8 columns, 640 threads
+//   M =  544 (FFT_H 1088, cfg2's own window): 2 x 17 x 16, 16 columns, 544 threads
+//   M = 2560 / 1760 / 1280 / 880 / 672 (transforms 5120 / 3520 / 2560 / 1760 / 1344): 8 x 20 x 16 (4 columns),
+//       8 x 10 x 22 (8), 8 x 10 x 16 (8), 5 x 8 x 22 (16), 6 x 8 x 14 (16)
+#define FC_FAST_COL_CONFIGS_G0(X) \
+    X(4224, 8, 24, 22, 4, 768)    \
+    X(3072, 8, 24, 16, 4, 768)    \
+    X(2560, 8, 20, 16, 4, 640)    \
+    X(2112, 8, 12, 22, 8, 768)    \
+    X(2080, 8, 10, 26, 8, 640)    \
+    X(1760, 8, 10, 22, 8, 640)
+#define FC_FAST_COL_CONFIGS_G1(X) \
+    X(1536, 8, 12, 16, 8, 768)    \
+    X(1280, 8, 10, 16, 8, 640)    \
+    X(1056, 6, 8, 22, 16, 768)    \
+    X(880, 5, 8, 22, 16, 640)     \
+    X(768, 6, 8, 16, 16, 768)     \
+    X(672, 6, 8, 14, 16, 768)     \
+    X(576, 6, 8, 12, 16, 768)     \
+    X(544, 2, 17, 16, 16, 544)    \
+    X(384, 4, 6, 16, 16, 384)     \
+    X(288, 4, 6, 12, 16, 384)     \
     X(144, 4, 6, 6, 16, 384)
+#define FC_FAST_COL_CONFIGS(X) FC_FAST_COL_CONFIGS_G0(X) FC_FAST_COL_CONFIGS_G1(X)
+constexpr int FC_COL_GROUPS = 2;
+#define FC_COL_CONFIGS_OF_GROUP(G, X)                                   \
+    do {                                                                \
+        if constexpr ((G) == 0) { FC_FAST_COL_CONFIGS_G0(X) }           \
+        else { FC_FAST_COL_CONFIGS_G1(X) }                              \
+    } while (0)
 
 struct FastColsInfo {
     bool ok = false;
@@ -189,20 +269,32 @@ inline FastColsInfo fast_cols_lookup(int M) {
 }
 
 inline bool fast_cols_length(int M, int) { return fast_cols_lookup(M).ok; }
+inline double fast_cols_factor(int M, int) {
+    if (!fast_cols_lookup(M).ok) return 0.0;
+    if (M == 544) return FC_FACTOR_1088;
+    if (M == 2080) return FC_FACTOR_4160;
+    return 0.45;
+}
 
 // Forward column kernel (fast_cols_fwd.hpp): same configurations; NZ2 = 3 (pruned, short kernels)
 // or R2 (any input length).  run.template go<Cfg, NZ2>().
-template <class Runner>
-inline bool fast_cols_fwd_dispatch(int M, int T, bool pruned, Runner&& run) {
+template <int G, class Runner>
+inline bool fast_cols_fwd_dispatch_group(int M, int T, bool pruned, Runner&& run) {
 #define FC_X(MM, A, B, C, TT, NTT)                                       \
     if (M == MM && T == TT) {                                            \
-        if (pruned) run.template go<ColCfg<MM, A, B, C, TT, NTT>, 3>();  \
-        else run.template go<ColCfg<MM, A, B, C, TT, NTT>, B>();         \
+        if constexpr (B > 3) {                                           \
+            if (pruned) { run.template go<ColCfg<MM, A, B, C, TT, NTT>, 3>(); return true; }  \
+        }                                                                \
+        run.template go<ColCfg<MM, A, B, C, TT, NTT>, B>();              \
         return true;                                                     \
     }
-    FC_FAST_COL_CONFIGS(FC_X)
+    FC_COL_CONFIGS_OF_GROUP(G, FC_X);
 #undef FC_X
     return false;
+}
+template <class Runner>
+inline bool fast_cols_fwd_dispatch(int M, int T, bool pruned, Runner&& run) {
+    return fast_cols_fwd_dispatch_group<0>(M, T, pruned, run) || fast_cols_fwd_dispatch_group<1>(M, T, pruned, run);
 }
 
 // may the pruned variant take columns of h_in samples?  (one non-zero input per stage-1 butterfly,
@@ -212,16 +304,20 @@ inline bool fast_cols_fwd_pruned_ok(const FastColsInfo& fi, int h_in) {
     return fi.R2 > 3 && nz <= m1 && nz <= 3 * fi.R3;
 }
 
-template <class Runner>
-inline bool fast_cols_dispatch(int M, int T, Runner&& run) {
+template <int G, class Runner>
+inline bool fast_cols_dispatch_group(int M, int T, Runner&& run) {
 #define FC_X(MM, A, B, C, TT, NTT)                          \
     if (M == MM && T == TT) {                               \
         run.template go<ColCfg<MM, A, B, C, TT, NTT>>();    \
         return true;                                        \
     }
-    FC_FAST_COL_CONFIGS(FC_X)
+    FC_COL_CONFIGS_OF_GROUP(G, FC_X);
 #undef FC_X
     return false;
+}
+template <class Runner>
+inline bool fast_cols_dispatch(int M, int T, Runner&& run) {
+    return fast_cols_dispatch_group<0>(M, T, run) || fast_cols_dispatch_group<1>(M, T, run);
 }
 
 // Sliced tail round of the output kernel (fast_cols.hpp, SLICED): for the small transforms (M <= 1056: the launches of

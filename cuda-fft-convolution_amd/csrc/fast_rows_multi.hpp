@@ -32,6 +32,9 @@ struct RowMultiState {
     int yoff[C::RND1];   // tiled intermediate: element offset of this thread's rows (same for every map)
 };
 
+// columns per tile of the tiled intermediate (pipeline.hpp: Geometry::y_tile_w)
+constexpr int FC_Y_TILE_W = 16, FC_Y_TILE_SHIFT = 4;
+
 // LINEAR (chosen by the launcher with fast_rows_multi_linear): see P5.
 inline bool fast_rows_multi_linear(const FastRowsArgs& g, int L, int m1) {
     const bool tiled = g.y_row_of != nullptr;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,10 @@ std::set<const fftconv_plan*> g_live_plans;
 constexpr size_t kOptionsMinSize = offsetof(fftconv_plan_options, exact_window) + sizeof(int);
 bool options_no_blockwise(const fftconv_plan_options* o) {
     return o && o->struct_size >= offsetof(fftconv_plan_options, blockwise) + sizeof(int) && o->blockwise == 1;
+}
+
+bool options_verbose(const fftconv_plan_options* o) {
+    return o && o->struct_size >= offsetof(fftconv_plan_options, verbose) + sizeof(int) && o->verbose != 0;
 }
 
 PlanTuning tuning_from(const fftconv_plan_options* o) {
@@ -359,6 +364,7 @@ struct fftconv_plan {
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
     long opt_host_chunk_kb = 0;    // ring chunk size (0 = auto)
     long opt_host_slots = 0;       // ring chunks (0 = auto)
+    long opt_defer_prepare = 0;    // 1: fftconv_plan_prepare_kernels_packed only records its request (see `deferred`)
     long opt_verbose = 0;          // 1: per-stage sizes and launch shapes to stderr (the reference's `debug`, src/cudaConvolutionFFT.cu:9)
     HostRing* ring = nullptr;      // created on the first host-output convolve
     bool profile = false;
@@ -1026,9 +1032,157 @@ int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const in
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Plan cache of the one-shot entries (include/fftconv.h).  The reference pays plan creation, six cudaMallocs and
+// the teardown in every MEX call (src/cudaConvolutionFFT.cu:127-142,144-185,302-310); a cached plan keeps its
+// tables, its device scratch (sized by the first call) and its host copy threads.  The cache object is never
+// destroyed (plans own joinable threads and HIP objects: nothing of that may run from a static destructor at
+// process exit, after the HIP runtime has gone) -- fftconv_cache_clear() is the release.
+// ---------------------------------------------------------------------------------------------------------
+struct CacheKey {
+    int H, W, F, mkh, mkw, gpu;
+    int kernel_path, rows_group, max_transform, exact_window, blockwise;
+    bool operator==(const CacheKey& o) const {
+        return H == o.H && W == o.W && F == o.F && mkh == o.mkh && mkw == o.mkw && gpu == o.gpu && kernel_path == o.kernel_path &&
+               rows_group == o.rows_group && max_transform == o.max_transform && exact_window == o.exact_window && blockwise == o.blockwise;
+    }
+};
+struct CacheEntry {
+    CacheKey key;
+    fftconv_plan* plan;
+    unsigned long stamp;
+    size_t bytes;
+};
+struct PlanCache {
+    std::mutex m;
+    std::vector<CacheEntry> idle;     // plans no call is using (a plan in use is simply not in here)
+    int max_plans = 4;
+    size_t max_bytes = (size_t)48 << 30;
+    unsigned long clock = 0;
+    long hits = 0, misses = 0;
+};
+PlanCache& plan_cache() {
+    static PlanCache* c = new PlanCache();
+    return *c;
+}
+
+CacheKey cache_key(int H, int W, int F, int mkh, int mkw, int gpu, const fftconv_plan_options* o) {
+    CacheKey k{H, W, F, mkh, mkw, gpu, 0, 0, 0, 0, 0};
+    if (o && o->struct_size >= kOptionsMinSize) {
+        k.kernel_path = o->kernel_path; k.rows_group = o->rows_group <= 0 ? 0 : o->rows_group;
+        k.max_transform = o->max_transform > 0 ? o->max_transform : 0; k.exact_window = o->exact_window != 0;
+        k.blockwise = options_no_blockwise(o) ? 1 : 0;
+    }
+    return k;
+}
+
+size_t plan_device_bytes(const fftconv_plan* p) {
+    size_t b = p->tw_m.bytes() + p->tw_w.bytes() + p->pairs.bytes() + p->S.bytes() + p->A.bytes() + p->Y.bytes() + p->K.bytes() + p->KF.bytes() +
+               p->O.bytes() + p->OC.bytes() + p->I.bytes() + p->NS.bytes();
+    if (const TiledState* ts = p->tiled) {
+        b += ts->specs.bytes() + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes();
+        if (ts->sub) b += plan_device_bytes(ts->sub);
+    }
+    return b;
+}
+
+// a cached idle plan for this key, or nullptr
+fftconv_plan* cache_take(const CacheKey& key) {
+    PlanCache& c = plan_cache();
+    std::lock_guard<std::mutex> lk(c.m);
+    for (size_t i = 0; i < c.idle.size(); i++)
+        if (c.idle[i].key == key) {
+            fftconv_plan* p = c.idle[i].plan;
+            c.idle.erase(c.idle.begin() + (long)i);
+            c.hits++;
+            return p;
+        }
+    c.misses++;
+    return nullptr;
+}
+
+// hand a plan (back) to the cache; plans pushed out by the limits are destroyed (outside the lock)
+void cache_put(const CacheKey& key, fftconv_plan* p) {
+    PlanCache& c = plan_cache();
+    std::vector<fftconv_plan*> drop;
+    {
+        std::lock_guard<std::mutex> lk(c.m);
+        if (c.max_plans <= 0) drop.push_back(p);
+        else {
+            c.idle.push_back(CacheEntry{key, p, ++c.clock, plan_device_bytes(p)});
+            auto total = [&] { size_t t = 0; for (const CacheEntry& e : c.idle) t += e.bytes; return t; };
+            while (!c.idle.empty() && ((int)c.idle.size() > c.max_plans || (c.idle.size() > 1 && total() > c.max_bytes))) {
+                size_t lru = 0;
+                for (size_t i = 1; i < c.idle.size(); i++)
+                    if (c.idle[i].stamp < c.idle[lru].stamp) lru = i;
+                drop.push_back(c.idle[lru].plan);
+                c.idle.erase(c.idle.begin() + (long)lru);
+            }
+        }
+    }
+    for (fftconv_plan* d : drop) fftconv_plan_destroy(d);
+}
+
+thread_local fftconv_call_timing g_call_timing = {0, 0, 0, 0, 0, 0};
+double ms_since(const std::chrono::steady_clock::time_point& t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 }  // namespace
 
 extern "C" {
+
+int fftconv_cache_configure(int max_plans, size_t max_bytes) {
+    if (max_plans < 0) return fail(FFTCONV_ERR_INVALID_ARG, "max_plans must not be negative");
+    std::vector<fftconv_plan*> drop;
+    {
+        PlanCache& c = plan_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        c.max_plans = max_plans;
+        if (max_bytes) c.max_bytes = max_bytes;
+        while ((int)c.idle.size() > c.max_plans) {
+            size_t lru = 0;
+            for (size_t i = 1; i < c.idle.size(); i++)
+                if (c.idle[i].stamp < c.idle[lru].stamp) lru = i;
+            drop.push_back(c.idle[lru].plan);
+            c.idle.erase(c.idle.begin() + (long)lru);
+        }
+    }
+    for (fftconv_plan* d : drop) fftconv_plan_destroy(d);
+    return 0;
+}
+
+int fftconv_cache_clear(void) {
+    std::vector<CacheEntry> drop;
+    {
+        PlanCache& c = plan_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        drop.swap(c.idle);
+    }
+    int rc = 0;
+    for (CacheEntry& e : drop)
+        if (int r = fftconv_plan_destroy(e.plan)) rc = r;
+    return rc;
+}
+
+int fftconv_cache_stats(long* plans, long* hits, long* misses, size_t* device_bytes) {
+    PlanCache& c = plan_cache();
+    std::lock_guard<std::mutex> lk(c.m);
+    if (plans) *plans = (long)c.idle.size();
+    if (hits) *hits = c.hits;
+    if (misses) *misses = c.misses;
+    if (device_bytes) {
+        *device_bytes = 0;
+        for (const CacheEntry& e : c.idle) *device_bytes += e.bytes;
+    }
+    return 0;
+}
+
+int fftconv_last_call_timing(fftconv_call_timing* timing) {
+    if (!timing) return fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
+    *timing = g_call_timing;
+    return 0;
+}
 
 int fftconv_fft_size16(int data_size) { return fft_size16(data_size); }
 int fftconv_fft_size_pow2(int data_size) { return fft_size_pow2(data_size); }
@@ -1072,6 +1226,7 @@ int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feat
         return fail(FFTCONV_ERR_INVALID_ARG, "fftconv_plan_options.struct_size is not set");
     }
     const PlanTuning tune = tuning_from(options);
+    p->opt_verbose = options_verbose(options) ? 1 : 0;
     p->gpu_id = gpu_id;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, tune)) {
@@ -1380,7 +1535,7 @@ int fftconv_plan_prepare_kernels_packed(fftconv_plan* plan, int n_kernel, const 
     if (int rc = p->A.ensure(bs.per_a * bs.nbA)) return rc;
     p->prepared.dk = nullptr;
     const bool timed_apart = p->profile && (p->profile_mask & ((1u << PK_KERNEL_COLS) | (1u << PK_IMAGE_COLS)));   // per-kind figures wanted
-    if (p->g.fast_fwd && !p->opt_flip_kernels && !timed_apart) {   // deferred: rides in the launch of the next image's column pass
+    if (p->opt_defer_prepare && p->g.fast_fwd && !p->opt_flip_kernels && !timed_apart) {   // deferred: rides in the launch of the next image's column pass
         p->deferred.on = true; p->deferred.dk = kernels_device; p->deferred.n = n_kernel; p->deferred.na = std::min(bs.nbA, n_kernel);
         p->deferred.kh = kernel_h; p->deferred.kw = kernel_w; p->deferred.stream = p->stream;
         return 0;
@@ -1482,6 +1637,14 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         return 0;
     }
     if (!strcmp(name, "verbose")) { plan->opt_verbose = value != 0; return 0; }
+    if (!strcmp(name, "defer_prepare")) {
+        if (!value && plan->deferred.on) {
+            if (int rc = use_device(plan)) return rc;
+            if (int rc = flush_pending_prepare(plan)) return rc;
+        }
+        plan->opt_defer_prepare = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "profile_kinds")) { plan->profile_mask = value <= 0 ? ~0u : (unsigned)value; return 0; }
     if (!strcmp(name, "rows_group")) { plan->g.rows_group = value <= 0 ? -1 : (int)value; return 0; }
 #if FC_ROWS_TIMELINE || FC_COLS_TIMELINE
@@ -1532,6 +1695,9 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "tuned_candidates")) { *value = plan->tuned_candidates; return 0; }
     if (!strcmp(name, "tuned_best")) { *value = plan->tuned_best; return 0; }
     if (!strcmp(name, "rows_group")) { *value = plan->g.rows_group; return 0; }
+    // read-only: which passes of this plan run on specialised (compile-time) kernels: bit 0 the spectral rows (w), bit 1 the
+    // column passes (h: image / kernel columns forwards, output columns); 3 = no generic kernel runs
+    if (!strcmp(name, "specialised_kernels")) { *value = (plan->g.fast_rows.ok ? 1 : 0) | (plan->g.fast_cols.ok ? 2 : 0); return 0; }
     if (!strcmp(name, "rows_slots_per_cu")) { *value = plan->g.rows_slots_per_cu; return 0; }   // read-only: resident row workgroups per CU
     if (!strcmp(name, "host_stream")) { *value = plan->opt_host_stream; return 0; }
     if (!strcmp(name, "host_min_kb")) { *value = plan->opt_host_min_kb; return 0; }
@@ -1539,6 +1705,8 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "flip_kernels")) { *value = plan->opt_flip_kernels; return 0; }
     if (!strcmp(name, "profile")) { *value = plan->profile ? 1 : 0; return 0; }
     if (!strcmp(name, "verbose")) { *value = plan->opt_verbose; return 0; }
+    if (!strcmp(name, "defer_prepare")) { *value = plan->opt_defer_prepare; return 0; }
+    if (!strcmp(name, "prepare_pending")) { *value = plan->deferred.on ? 1 : 0; return 0; }   // read-only: a recorded, not yet launched preparation
     return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
@@ -1583,14 +1751,43 @@ int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int fe
                             "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
     if (fft_h) *fft_h = fft_size16(data_h + max_kernel_h - 1);
     if (fft_w) *fft_w = fft_size16(data_w + max_kernel_w - 1);
-    fftconv_plan* p = nullptr;
+    // the plan: from the cache (same problem, device and options as an earlier call), else built now.
     // (sizes beyond one single-pass plan: the plan is block-wise -- overlap-add over ordinary plans -- by itself)
-    if (int rc = fftconv_plan_create_ex(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr, options)) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    fftconv_call_timing tm = {0, 0, 0, 0, 0, 0};
+    if (gpu_id < 0) {
+        int ndev = 0;
+        if (int rc = fftconv_device_count(&ndev)) return rc;
+        HIP_TRY(hipGetDevice(&gpu_id));
+    }
+    const CacheKey key = cache_key(data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, options);
+    fftconv_plan* p = cache_take(key);
+    tm.cache_hit = p ? 1 : 0;
+    if (!p)
+        if (int rc = fftconv_plan_create_ex(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr, options)) return rc;
+    (void)fftconv_plan_set_option(p, "verbose", options_verbose(options) ? 1 : 0);
+    tm.plan_ms = ms_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
     int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);
+    tm.image_ms = ms_since(t1);
+    const auto t2 = std::chrono::steady_clock::now();
     if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, kernel_location, out, FFTCONV_HOST);
+    tm.convolve_ms = ms_since(t2);
+    const auto t3 = std::chrono::steady_clock::now();
     std::string keep = g_last_error;
-    fftconv_plan_destroy(p);
+    // argument-class failures were found before anything was queued and leave the plan as it was; after a HIP or
+    // allocation failure the plan is not trusted again
+    const bool reusable = rc == 0 || rc == FFTCONV_ERR_INVALID_ARG || rc == FFTCONV_ERR_KERNEL_SHAPE || rc == FFTCONV_ERR_KERNEL_EXCEEDS_MAX ||
+                          rc == FFTCONV_ERR_THREAD_SIZE;
+    if (reusable) cache_put(key, p);
+    else fftconv_plan_destroy(p);
     if (rc) g_last_error = keep;
+    tm.release_ms = ms_since(t3);
+    tm.total_ms = ms_since(t0);
+    g_call_timing = tm;
+    if (options_verbose(options))
+        fprintf(stderr, "fftconv: one-shot call %.3f ms = plan %.3f (%s) + image %.3f + %d kernels %.3f + release %.3f\n", tm.total_ms, tm.plan_ms,
+                tm.cache_hit ? "cached" : "created", tm.image_ms, n_kernel, tm.convolve_ms, tm.release_ms);
     return rc;
 }
 

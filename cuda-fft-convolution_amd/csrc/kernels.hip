@@ -139,6 +139,84 @@ hipError_t launch_crop_maps(const float* src, int src_h, size_t src_map_stride, 
     return hipGetLastError();
 }
 
+// ---- the specialised kernels: their translation units (kernels_*_g<G>.hip) hold one group of configurations each; the
+// ---- first group that has the length takes the launch
+#define FC_DECL_GROUP(G)                                                                                                              \
+    hipError_t launch_fast_rows_fwd_g##G(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s, bool* matched);                   \
+    hipError_t launch_fast_rows_g##G(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s, bool* matched); \
+    hipError_t launch_fast_rows_multi_g##G(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s, bool* matched); \
+    hipError_t fast_rows_multi_wgs_per_cu_g##G(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu);
+FC_DECL_GROUP(0) FC_DECL_GROUP(1) FC_DECL_GROUP(2)
+#undef FC_DECL_GROUP
+#define FC_DECL_GROUP(G)                                                                                                              \
+    hipError_t launch_fast_cols_g##G(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s, bool* matched);                 \
+    hipError_t launch_fast_cols_fwd_g##G(int M, int T, bool pruned, const FastColsFwdArgs& a, int num_cus, hipStream_t s, bool* matched); \
+    hipError_t launch_fast_cols_fwd_pair_g##G(int M, int T, const FastColsFwdArgs& image, const FastColsFwdArgs& kernels, bool kernels_pruned, \
+                                              int num_cus, hipStream_t s, bool* matched);
+FC_DECL_GROUP(0) FC_DECL_GROUP(1)
+#undef FC_DECL_GROUP
+static_assert(FC_ROW_GROUPS == 3 && FC_COL_GROUPS == 2, "one translation unit per group: keep kernels.hip and the Makefile in step");
+
+hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    bool m = false;
+    hipError_t e = launch_fast_rows_fwd_g0(L, a, rows, s, &m);
+    if (!m) e = launch_fast_rows_fwd_g1(L, a, rows, s, &m);
+    if (!m) e = launch_fast_rows_fwd_g2(L, a, rows, s, &m);
+    return e;
+}
+
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s) {
+    if (rows <= 0 || kernels <= 0) return hipSuccess;
+    bool m = false;
+    hipError_t e = launch_fast_rows_g0(L, nz2, a, rows, kernels, order, s, &m);
+    if (!m) e = launch_fast_rows_g1(L, nz2, a, rows, kernels, order, s, &m);
+    if (!m) e = launch_fast_rows_g2(L, nz2, a, rows, kernels, order, s, &m);
+    return e;
+}
+
+hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s) {
+    if (rows <= 0 || kernels <= 0) return hipSuccess;
+    if (a.F < 1 || kernels_per_wg < 1) return hipErrorInvalidValue;
+    bool m = false;
+    hipError_t e = launch_fast_rows_multi_g0(L, nz2, a, rows, kernels, kernels_per_wg, s, &m);
+    if (!m) e = launch_fast_rows_multi_g1(L, nz2, a, rows, kernels, kernels_per_wg, s, &m);
+    if (!m) e = launch_fast_rows_multi_g2(L, nz2, a, rows, kernels, kernels_per_wg, s, &m);
+    return e;
+}
+
+hipError_t fast_rows_multi_wgs_per_cu(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu) {
+    hipError_t e = fast_rows_multi_wgs_per_cu_g0(L, nz2, a, wgs_per_cu);
+    if (e == hipErrorInvalidValue) e = fast_rows_multi_wgs_per_cu_g1(L, nz2, a, wgs_per_cu);
+    if (e == hipErrorInvalidValue) e = fast_rows_multi_wgs_per_cu_g2(L, nz2, a, wgs_per_cu);
+    return e;
+}
+
+hipError_t launch_fast_cols(int M, int T, const FastColsArgs& a, int num_cus, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    bool m = false;
+    hipError_t e = launch_fast_cols_g0(M, T, a, num_cus, s, &m);
+    if (!m) e = launch_fast_cols_g1(M, T, a, num_cus, s, &m);
+    return e;
+}
+
+hipError_t launch_fast_cols_fwd(int M, int T, bool pruned, const FastColsFwdArgs& a, int num_cus, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    bool m = false;
+    hipError_t e = launch_fast_cols_fwd_g0(M, T, pruned, a, num_cus, s, &m);
+    if (!m) e = launch_fast_cols_fwd_g1(M, T, pruned, a, num_cus, s, &m);
+    return e;
+}
+
+hipError_t launch_fast_cols_fwd_pair(int M, int T, const FastColsFwdArgs& image, const FastColsFwdArgs& kernels, bool kernels_pruned,
+                                     int num_cus, hipStream_t s) {
+    if (image.ntiles <= 0 || kernels.ntiles <= 0) return hipErrorInvalidValue;
+    bool m = false;
+    hipError_t e = launch_fast_cols_fwd_pair_g0(M, T, image, kernels, kernels_pruned, num_cus, s, &m);
+    if (!m) e = launch_fast_cols_fwd_pair_g1(M, T, image, kernels, kernels_pruned, num_cus, s, &m);
+    return e;
+}
+
 hipError_t kernels_init() {
     const int lim = 160 * 1024;
     hipError_t e;

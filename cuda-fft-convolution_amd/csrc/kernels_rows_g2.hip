@@ -1,0 +1,4 @@
+// kernels_rows_g2.hip -- one-map spectral-row and forward image-row kernels, configurations of group 2 of fast_paths.hpp
+// (the kernel families are spread over translation units only to compile in parallel: make -j).
+#define FC_TU_GROUP 2
+#include "kernels_rows.inc"

@@ -1,0 +1,4 @@
+// kernels_rows_multi_g2.hip -- multi-map spectral-row kernels, configurations of group 2 of fast_paths.hpp
+// (the kernel families are spread over translation units only to compile in parallel: make -j).
+#define FC_TU_GROUP 2
+#include "kernels_rows_multi.inc"

@@ -55,8 +55,8 @@ struct Geometry {
     // tiled intermediate [w / 16][row][16] (one 128-byte line per row and tile), rows of bins
     // (k, M-k) adjacent so that the output kernel merges them while landing: both hot kernels
     // specialised and the window a whole number of layout tiles
-    static constexpr int y_tile_w = 16;
-    static constexpr int y_tile_shift = 4;
+    static constexpr int y_tile_w = FC_Y_TILE_W;
+    static constexpr int y_tile_shift = FC_Y_TILE_SHIFT;
     bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
     int tile_rows() const { return y_tiled() ? M + 2 : rows; }
     int rows_wg_order = 0;     // workgroup order of the one-map row kernel (kernels_rows.hip: k_fast_rows); 2 for F > 1
@@ -126,7 +126,7 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     g.fft_h = fft_size16(H + max_kh - 1);
     g.fft_w = fft_size16(W + max_kw - 1);
     LengthPrefs prefs;   // the planner prefers lengths with specialised kernels (able to take max_kw)
-    if (allow_fast) { prefs.fast_rows = &fast_rows_length; prefs.fast_cols = &fast_cols_length; prefs.max_kw = max_kw; }
+    if (allow_fast) { prefs.fast_rows = &fast_rows_factor; prefs.fast_cols = &fast_cols_factor; prefs.max_kw = max_kw; }
     g.Lh = choose_length(H + max_kh - 1, true, g.fft_h, prefs);
     g.Lw = choose_length(W + max_kw - 1, false, g.fft_w, prefs);
     if (tune.exact_window) {

@@ -78,12 +78,14 @@ inline std::vector<int> factorize(int L) {
 inline bool length_supported(int L) { return L == 1 || !factorize(L).empty(); }
 
 // Lengths for which a specialised kernel exists (fast_paths.hpp) run ~2.5x faster than the generic
-// kernels.  The predicates come from fast_paths.hpp through this struct so that this header stays
+// kernels.  The cost factors come from fast_paths.hpp through this struct so that this header stays
 // independent of it (nullptr: no preference); `ctx` is the widest kernel the row kernel must take.
-using LengthPredicate = bool (*)(int L, int ctx);
+// A factor is the measured cost per point of that length's specialised kernels relative to the generic
+// estimate below (0: the length has none).
+using LengthFactor = double (*)(int L, int ctx);
 struct LengthPrefs {
-    LengthPredicate fast_rows = nullptr;   // w direction (complex transform of length L)
-    LengthPredicate fast_cols = nullptr;   // h direction (complex transform of length L / 2)
+    LengthFactor fast_rows = nullptr;   // w direction (complex transform of length L)
+    LengthFactor fast_cols = nullptr;   // h direction (complex transform of length L / 2)
     int max_kw = 1;
 };
 
@@ -94,7 +96,8 @@ inline double length_cost(int L, bool real_half, const LengthPrefs& prefs) {
     if (Lc != 1 && r.empty()) return 1e30;
     double c = 40.0 + (real_half ? 10.0 : 0.0);
     for (int x : r) c += radix_cost(x) * (real_half ? 0.5 : 1.0);
-    if (real_half ? (prefs.fast_cols && prefs.fast_cols(Lc, 0)) : (prefs.fast_rows && prefs.fast_rows(L, prefs.max_kw))) c *= 0.45;
+    const double f = real_half ? (prefs.fast_cols ? prefs.fast_cols(Lc, 0) : 0.0) : (prefs.fast_rows ? prefs.fast_rows(L, prefs.max_kw) : 0.0);
+    if (f > 0.0) c *= f;
     return c * (double)L;
 }
 

@@ -22,8 +22,15 @@
 #define FFTCONV_MEX_GPU 0
 #endif
 
+// The reference creates its cuFFT plans and device buffers in every call and frees them before it returns
+// (src/cudaConvolutionFFT.cu:127-185,302-310); the library keeps the plans of the last few problems instead
+// (fftconv.h, plan cache) and this hook releases them when MATLAB clears the MEX file or exits.
+static void release_cached_plans(void) { (void)fftconv_cache_clear(); }
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const char* errId = FFTCONV_MEX_ERROR_ID;  // "cudaConvFFTData:InvalidInput" (reference :30)
+    static bool hooked = false;
+    if (!hooked) { mexAtExit(release_cached_plans); hooked = true; }
 #if FFTCONV_MEX_GPU
     mxInitGPU();                                                                             // :40
 #endif

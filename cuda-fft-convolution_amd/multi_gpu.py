@@ -22,6 +22,7 @@ the host emulator:
     engine.new_image_buffer() / engine.upload(buf, host_image)      (image streaming only)
 """
 import contextlib
+import time
 
 
 def filter_shard(n_filters, rank, world):
@@ -91,8 +92,12 @@ class FilterShardedConvolver:
     step k, which takes the image transform and the broadcast off the critical path of every step
     but the first.  A buffer is overwritten only after the convolve that read it (events)."""
 
-    def __init__(self, engine, dist, rank, world, n_filters, src=0, depth=2, always_collective=False):
+    def __init__(self, engine, dist, rank, world, n_filters, src=0, depth=2, always_collective=False, time_broadcast=None):
+        """time_broadcast: None, "wall" (host clock around the call: backends that block the host, gloo) or "event"
+        (an event pair on the side stream around it: nccl); broadcast_ms() returns what was measured."""
         self.engine, self.dist, self.rank, self.world, self.src = engine, dist, rank, world, src
+        self.time_broadcast = time_broadcast
+        self._bc_wall, self._bc_events = [], []
         self.first, self.count = filter_shard(n_filters, rank, world)
         self.depth = max(1, int(depth))
         self.collective = world > 1 or always_collective
@@ -125,10 +130,32 @@ class FilterShardedConvolver:
             if self.collective:
                 # the single collective of the path; issued from the side stream: the backend orders
                 # it behind the transform above and wait() orders the side stream behind it
+                t0 = ev0 = None
+                if self.time_broadcast == "wall":
+                    t0 = time.perf_counter()
+                elif self.time_broadcast == "event":
+                    torch = self.engine.torch
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record(torch.cuda.current_stream())
                 work = self.dist.broadcast(self.spec[b], src=self.src, async_op=True)
                 work.wait()
+                if t0 is not None:
+                    self._bc_wall.append((time.perf_counter() - t0) * 1e3)
+                elif ev0 is not None:
+                    ev1.record(torch.cuda.current_stream())
+                    self._bc_events.append((ev0, ev1))
             s.record(self.ready[b], side=True)
         self.n_sub += 1
+
+    def broadcast_ms(self, reset=True):
+        """milliseconds of every broadcast timed since the last reset (device events are synchronised here)"""
+        out = list(self._bc_wall)
+        for ev0, ev1 in self._bc_events:
+            ev1.synchronize()
+            out.append(ev0.elapsed_time(ev1))
+        if reset:
+            self._bc_wall, self._bc_events = [], []
+        return out
 
     def convolve(self):
         if self.n_conv >= self.n_sub:
@@ -169,8 +196,10 @@ class ImageStreamedConvolver:
     """This rank's images against all kernels, H2D of image i + 1 (side stream, two device
     buffers) behind the compute of image i.  No collective: ranks are independent."""
 
-    def __init__(self, engine, n_filters):
+    def __init__(self, engine, n_filters, time_uploads=False):
         self.engine, self.n_filters = engine, n_filters
+        self.time_uploads = time_uploads       # an event pair on the side stream around every image's H2D copy (upload_ms())
+        self._up_events = []
         self.spec = engine.new_spectrum()
         self.buf = [engine.new_image_buffer() for _ in range(2)]
         s = engine.sync
@@ -183,8 +212,25 @@ class ImageStreamedConvolver:
         s = self.engine.sync
         with s.side():
             s.wait(self.consumed[b], side=True)     # also across run() calls: the buffer's last reader
+            ev0 = None
+            if self.time_uploads:
+                torch = self.engine.torch
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream())
             self.engine.upload(self.buf[b], host_image)
+            if ev0 is not None:
+                ev1.record(torch.cuda.current_stream())
+                self._up_events.append((ev0, ev1))
             s.record(self.copied[b], side=True)
+
+    def upload_ms(self, reset=True):
+        out = []
+        for ev0, ev1 in self._up_events:
+            ev1.synchronize()
+            out.append(ev0.elapsed_time(ev1))
+        if reset:
+            self._up_events = []
+        return out
 
     def run(self, host_images, on_result=None):
         host_images = list(host_images)
@@ -214,9 +260,15 @@ class ImageStreamedConvolver:
 class HipPlanEngine:
     """Engine over one fftconv Plan (HIP kernels) with device-resident kernels and maps, through
     torch tensors for memory and streams.  `kernels` is this rank's block, packed [n][F][kw][kh];
-    convolve() returns the device tensor [n][FFT_W][FFT_H] it fills (reused by every call)."""
+    convolve() returns the device tensor [n][FFT_W][FFT_H] it fills (reused by every call).
 
-    def __init__(self, torch, fc, plan, device, kernels, kh, kw, first=0, main_stream=None, overlap=True, out=None):
+    `kernels_host` (a pinned host tensor of the same shape): the kernels are uploaded INSIDE every step, as the
+    reference's per-kernel loop does (cudaMemcpy of every kernel, src/cudaConvolutionFFT.cu:221-222; SURVEY 8(d) counts
+    it in the timed region) -- into two device buffers in turn, on an upload stream of their own, so that the copy for
+    step k + 1 runs beside the maps of step k (events order buffer reuse behind the convolve that last read it)."""
+
+    def __init__(self, torch, fc, plan, device, kernels, kh, kw, first=0, main_stream=None, overlap=True, out=None,
+                 defer_prepare=False, kernels_host=None):
         self.torch, self.fc, self.plan, self.device = torch, fc, plan, device
         self.kernels, self.kh, self.kw, self.first = kernels, kh, kw, first
         self.count = int(kernels.shape[0])
@@ -229,6 +281,38 @@ class HipPlanEngine:
         # `out`: reuse another engine's map buffer (bench.py times a second, default-options plan into the same maps)
         self.out = out if out is not None else torch.empty((max(1, self.count), info.fft_w, info.fft_h), dtype=torch.float32, device=device)
         self._keep = None
+        # defer_prepare: prepare_kernels only records its request and the kernels' column pass rides in the launch of
+        # the image transform that follows ON THE PLAN'S STREAM (one launch fewer per step: single-GPU steps without a
+        # side stream, image streaming).  Where the transform runs on a side stream or on another rank (filter
+        # sharding) the pass must be queued at once, ahead of the wait for the spectrum: the default.
+        plan.set_option("defer_prepare", 1 if defer_prepare else 0)
+        self.kernels_host = kernels_host if (kernels_host is not None and self.count) else None
+        self.uploads = 0
+        if self.kernels_host is not None:
+            self.kbuf = [kernels, torch.empty_like(kernels)]
+            self.up_stream = torch.cuda.Stream(device)
+            self.k_uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+            self.k_consumed = [torch.cuda.Event(), torch.cuda.Event()]
+            self.k_cur = 0
+            self.k_waited = False
+            self._upload(0)
+
+    # -- kernels uploaded per step
+    def _upload(self, b):
+        with self.torch.cuda.stream(self.up_stream):
+            self.up_stream.wait_event(self.k_consumed[b])      # never recorded = complete
+            self.kbuf[b].copy_(self.kernels_host, non_blocking=True)
+            self.k_uploaded[b].record(self.up_stream)
+        self.uploads += 1
+
+    def _kernels_ptr(self):
+        """device pointer of this step's kernels (ordering the plan's stream behind their upload once per step)"""
+        if self.kernels_host is None:
+            return self.kernels.data_ptr()
+        if not self.k_waited:
+            self.main_stream.wait_event(self.k_uploaded[self.k_cur])
+            self.k_waited = True
+        return self.kbuf[self.k_cur].data_ptr()
 
     def new_spectrum(self):
         return self.torch.empty(self.plan.info.spectrum_bytes, dtype=self.torch.uint8, device=self.device)
@@ -258,12 +342,17 @@ class HipPlanEngine:
     def prepare_kernels(self, first, count):
         assert (first, count) == (self.first, self.count)
         if count:
-            self.plan.prepare_kernels_packed_device(count, self.kernels.data_ptr(), self.kh, self.kw)
+            self.plan.prepare_kernels_packed_device(count, self._kernels_ptr(), self.kh, self.kw)
 
     def convolve(self, spec, first, count):
         assert (first, count) == (self.first, self.count), "engine was built for another filter block"
         self.plan.use_spectrum_buffer(spec.data_ptr(), spec.numel())
         self.plan.mark_spectrum_valid()
         if count:
-            self.plan.convolve_packed_device(count, self.kernels.data_ptr(), self.kh, self.kw, self.out.data_ptr())
+            self.plan.convolve_packed_device(count, self._kernels_ptr(), self.kh, self.kw, self.out.data_ptr())
+            if self.kernels_host is not None:      # this step's buffer is free once the convolve has read it; the next step's upload starts now
+                self.k_consumed[self.k_cur].record(self.main_stream)
+                self.k_cur ^= 1
+                self.k_waited = False
+                self._upload(self.k_cur)
         return self.out

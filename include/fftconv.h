@@ -88,7 +88,8 @@ int fftconv_device_count(int *count);
  *   out                                 plhs[0]  n_kernel caller buffers of FFT_H*FFT_W floats
  *                                                (the reference allocates them: :284-288)
  *   fft_h, fft_w                        out, nullable: the window size
- * Synchronous: results are complete on return, all device memory is released.
+ * Synchronous: results are complete on return.  The plan (tables, device scratch) goes back into the
+ * plan cache below instead of being torn down; fftconv_cache_clear() releases it.
  * Images whose padded size exceeds what one plan transforms in a single pass (the plan API
  * reports FFTCONV_ERR_UNSUPPORTED_SIZE) are convolved block-wise here: overlap-add over
  * ordinary plans, the block results summed on the device into the full FFT_H x FFT_W maps
@@ -114,6 +115,40 @@ int fftconv_convolution_fft_ex(const float *data, int data_h, int data_w, int fe
                                int gpu_id,
                                float *const *out, int *fft_h, int *fft_w,
                                const struct fftconv_plan_options *options);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan cache of the one-shot entries.  The reference builds its cuFFT plans, allocates its six device
+ * buffers and tears everything down inside every MEX call (src/cudaConvolutionFFT.cu:127-142,144-185,
+ * 302-310); here that state is a plan, and fftconv_convolution_fft / _ex (and with them the
+ * cudaConvolutionFFT gateway) keep the plans of their last few distinct problems -- key: data size, F,
+ * MAX_KERNEL, device, creation options -- with their tables, device scratch and host copy threads, so that
+ * a repeated call pays for the transfers and the kernels only (cfg2: 15.9 ms -> the reused-plan time).
+ * A plan is handed to one call at a time; a concurrent call with the same key builds a plan of its own.
+ * A call that fails with a HIP / allocation error does not return its plan to the cache.
+ *   fftconv_cache_configure  max_plans: plans kept (default 4; 0 switches the cache off and empties it),
+ *                            max_bytes: device memory the idle cached plans may hold together (default 48 GiB,
+ *                            0 = keep the current value); least recently used plans go first
+ *   fftconv_cache_clear      destroys every idle cached plan (device memory, host threads).  The gateways
+ *                            register it with mexAtExit; a process that unloads the library calls it first.
+ *   fftconv_cache_stats      nullable outputs: plans held now, hits / misses so far, device bytes held
+ * ------------------------------------------------------------------------------------------ */
+int fftconv_cache_configure(int max_plans, size_t max_bytes);
+int fftconv_cache_clear(void);
+int fftconv_cache_stats(long *plans, long *hits, long *misses, size_t *device_bytes);
+
+/* Where the time of this thread's last one-shot call (fftconv_convolution_fft / _ex) went, milliseconds of wall
+ * clock: what the reference spends in plan creation and allocation (src/cudaConvolutionFFT.cu:127-142,144-185), the
+ * image upload + transform (:146-169), the per-kernel loop with its copies (:204-291) and the teardown (:302-310).
+ * With plan option / fftconv_plan_options.verbose the same line goes to stderr. */
+typedef struct fftconv_call_timing {
+    double plan_ms;        /* cache lookup, or plan creation: tables, kernel set-up, device tables */
+    double image_ms;       /* host-to-device copy of the image + its transform, complete */
+    double convolve_ms;    /* kernel uploads, every map computed and copied into the caller's buffers */
+    double release_ms;     /* plan back into the cache, or its teardown */
+    double total_ms;
+    int cache_hit;         /* 1: the plan came from the cache */
+} fftconv_call_timing;
+int fftconv_last_call_timing(fftconv_call_timing *timing);
 
 /* ------------------------------------------------------------------------------------------
  * Plan API: the state the reference keeps inside one mexFunction call (cuFFT plans
@@ -171,6 +206,9 @@ typedef struct fftconv_plan_options {
                          *    field is accepted and means 0.)  fftconv_plan_get_option "blockwise" reads the number of
                          *    blocks of a plan (0 = single pass).  The reference plans cuFFT for any size:
                          *    src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98. */
+    int verbose;        /* 1: the plan starts with option "verbose" on (the reference's compile-time `debug`,
+                         *    src/cudaConvolutionFFT.cu:9), and a one-shot call prints where its time went
+                         *    (fftconv_call_timing).  (Appended in 0.3; a struct_size without it means 0.) */
 } fftconv_plan_options;
 int fftconv_plan_create_ex(fftconv_plan **plan, int data_h, int data_w, int feature_dim,
                            int max_kernel_h, int max_kernel_w, int gpu_id, void *hip_stream,
@@ -227,9 +265,13 @@ int fftconv_plan_convolve_packed(fftconv_plan *plan, int n_kernel, const float *
 
 /* Optional split of fftconv_plan_convolve_packed: queues only the part that does not depend on
  * the image (the h-transform of the kernels' columns, i.e. padData + the H half of cufftExecR2C on
- * the kernels, src/cudaConvolutionFFT.cu:245-255) so that it overlaps the arrival of the image
- * spectrum (the RCCL broadcast on the other ranks).  The next fftconv_plan_convolve_packed call
- * with the same arguments reuses it; any other use of the plan discards it. */
+ * the kernels, src/cudaConvolutionFFT.cu:245-255) on the plan's stream, at once, so that it overlaps
+ * the arrival of the image spectrum (the RCCL broadcast on the other ranks).  The next
+ * fftconv_plan_convolve_packed call with the same arguments reuses it; any other use of the plan discards it.
+ * With plan option "defer_prepare" = 1 the call only RECORDS the request: the pass then rides in the launch of
+ * the next fftconv_plan_set_image on the same stream (one launch fewer per step: what small problems want
+ * when the image transform follows on the same stream), or is launched by the next convolve / set_stream /
+ * synchronize -- the caller gives up the overlap above for it. */
 int fftconv_plan_prepare_kernels_packed(fftconv_plan *plan, int n_kernel, const float *kernels_device,
                                         int kernel_h, int kernel_w);
 
@@ -273,7 +315,9 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             per dimension, the window the reference's unused computeFFTsize would give
  *             (src/cudaConvFFTData.h:67-94): the convolution in its top-left corner, zeros elsewhere.
  *             Result buffers then hold out_h x out_w floats (fftconv_plan_get_info)),
- *          "verbose" (1: the sizes and launch shapes of every stage go to stderr as the work is queued -- the
+ *          "defer_prepare" (1: fftconv_plan_prepare_kernels_packed records its request instead of launching it, see
+             there; 0 (default): launched at once.  Read-only "prepare_pending": 1 while such a request waits),
+          "verbose" (1: the sizes and launch shapes of every stage go to stderr as the work is queued -- the
  *             reference's compile-time `debug` switch, src/cudaConvolutionFFT.cu:9,60,100,114,240,258; 0 (default) silent),
  *          "flip_kernels" (1: every kernel is flipped along h and w on the device before it is
  *             transformed, i.e. the plan correlates -- the "Flip Kernel (Required)" step of
@@ -282,7 +326,9 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
 int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
 /* Current value of an option, plus read-only ones: "tuned_candidates" (allocations tried by the last placement tuning)
  * and "tuned_best" (index of the one kept), "blockwise" (blocks of a block-wise plan, 0 = one pass),
- * "rows_slots_per_cu" (workgroups of the multi-map row kernel a CU holds at once: what the walk length is chosen for). */
+ * "rows_slots_per_cu" (workgroups of the multi-map row kernel a CU holds at once: what the walk length is chosen for),
+ * "specialised_kernels" (bit 0: the spectral-row pass runs on a specialised kernel, bit 1: the column passes do; 3 = no
+ * generic kernel runs for this plan). */
 int fftconv_plan_get_option(fftconv_plan *plan, const char *name, long *value);
 
 typedef struct fftconv_profile {

@@ -10,142 +10,12 @@
 #include <cstring>
 #include <vector>
 
-#include "pipeline.hpp"
+#include "emu_runners.hpp"
 
 using namespace fc;
+using namespace emu;
 
 namespace {
-struct HostCtx {
-    int tid = 0, nthreads = 1;
-    void sync() const {}
-};
-
-// Phase-structured bodies (fast_rows.hpp): every phase is run for all NT threads before the
-// next one starts, with one State per emulated thread.
-template <class State>
-struct HostPhaseCtx {
-    int NT;
-    std::vector<State> st;
-    explicit HostPhaseCtx(int nt) : NT(nt), st(nt) {}
-    template <class F>
-    void phase(F&& f) {
-        for (int t = 0; t < NT; t++) f(t, st[t]);
-    }
-    template <class F>
-    void phase_nosync(F&& f) {
-        for (int t = 0; t < NT; t++) f(t, st[t]);
-    }
-    template <bool NOSYNC, class F>
-    void phase_dbg(F&& f) {
-        for (int t = 0; t < NT; t++) f(t, st[t]);
-    }
-    // the GPU's lane exchange (DPP row_ror:8): the peer's value was produced in an earlier phase
-    template <class Acc>
-    c32 peer8(int t, Acc&& acc) {
-        return acc(st[t ^ 8]);
-    }
-};
-
-struct EmuFastRows {
-    const FastRowsArgs& a;
-    c32* lds;
-    int rows;
-    int group = 0;   // > 1: multi-map body; the emulator holds one kernel at a time, so the walk
-                     // over `group` maps is emulated with the same kernel (strides 0): the loop,
-                     // the prefetch slot and the LDS reuse are exercised, the indexing is not
-    template <class Cfg, int NZ2>
-    void go() {
-        if (group > 1) {
-            FastRowsArgs b = a;
-            b.a_kernel_stride = 0;
-            b.y_kernel_stride = 0;
-            for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
-                for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-                if (a.F > 1) {   // the walk over (map, feature) pairs
-                    HostPhaseCtx<RowMultiState<Cfg, true>> ctx(Cfg::NT);
-                    if (fast_rows_multi_linear(b, Cfg::L, Cfg::m1)) fast_rows_multi_body<Cfg, NZ2, true, true>(ctx, lds, b, grp, 0, group, rows);
-                    else fast_rows_multi_body<Cfg, NZ2, false, true>(ctx, lds, b, grp, 0, group, rows);
-                } else {
-                    HostPhaseCtx<RowMultiState<Cfg>> ctx(Cfg::NT);
-                    if (fast_rows_multi_linear(b, Cfg::L, Cfg::m1)) fast_rows_multi_body<Cfg, NZ2, true>(ctx, lds, b, grp, 0, group, rows);
-                    else fast_rows_multi_body<Cfg, NZ2, false>(ctx, lds, b, grp, 0, group, rows);
-                }
-            }
-            return;
-        }
-        for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
-            // poison the LDS image so that reads of never-written cells show up
-            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            if (a.F > 1) {
-                HostPhaseCtx<RowState<Cfg, true>> ctx(Cfg::NT);
-                fast_rows_body<Cfg, NZ2, true>(ctx, lds, a, grp, 0, rows);
-            } else {
-                HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
-                fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, grp, 0, rows);
-            }
-        }
-    }
-};
-
-struct EmuFastRowsFwd {
-    const FastRowsFwdArgs& a;
-    c32* lds;
-    int rows;
-    template <class Cfg>
-    void go() {
-        for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
-            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            HostPhaseCtx<RowFwdState> ctx(Cfg::NT);
-            fast_rows_fwd_body<Cfg>(ctx, lds, a, grp, rows);
-        }
-    }
-};
-
-struct EmuFastColsFwd {
-    const FastColsFwdArgs& a;
-    c32* lds;
-    int nwg;
-    template <class Cfg, int NZ2>
-    void go() {
-        for (int wg = 0; wg < nwg; wg++) {
-            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            HostPhaseCtx<ColFwdState> ctx(Cfg::NT);
-            fast_cols_fwd_body<Cfg, NZ2>(ctx, lds, a, wg, nwg);
-        }
-    }
-};
-
-struct EmuFastCols {
-    const FastColsArgs& a;
-    c32* lds;
-    int nwg;
-    template <class Cfg>
-    void go() {
-        FastColsArgs b = a;
-        int sgrid = 0;
-        // the emulator uses 8 "persistent workgroups" where the product's launcher would slice the tail round, so that the
-        // sliced body runs on the CPU tier too (e.g. 18 tiles = 2 full rounds of 8 + 2 tiles in 4 slices each)
-        const bool sliced = (Cfg::M <= FC_SLICE_MAX_M) && fast_cols_slice_plan(Cfg::M, Cfg::T, 8, b, sgrid);
-        const int loops = sliced ? 8 : nwg;
-        for (int wg = 0; wg < loops; wg++) {
-            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            if (a.y_tiled) {
-                HostPhaseCtx<ColPairState<Cfg>> pctx(Cfg::NT);
-                if constexpr (Cfg::M <= FC_SLICE_MAX_M) {
-                    if (sliced) {     // the tail round in column slices (fast_cols_slice_plan filled `b`)
-                        if (wg < sgrid) fast_cols_body<Cfg, true, true>(pctx, lds, b, wg, sgrid);
-                        continue;
-                    }
-                }
-                fast_cols_body<Cfg, true>(pctx, lds, a, wg, nwg);
-                continue;
-            }
-            HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
-            fast_cols_body<Cfg, false>(ctx, lds, a, wg, nwg);
-        }
-    }
-};
-
 PlanTuning g_tune;   // path mode / rows group of the emulated plans (pipeline.hpp PlanTuning)
 }  // namespace
 
@@ -177,7 +47,7 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
         d.fc_tw1 = t.fcl.tw1.data(); d.fc_tw2 = t.fcl.tw2.data(); d.fc_pairs = t.fcl.pairs.data();
         FastColsFwdArgs fa = fast_cols_fwd_args(g, d, data, (size_t)H * W, H, H, W, F, S, (size_t)g.rows * g.s_pitch, g.s_pitch);
         EmuFastColsFwd run{fa, lds.data(), 3};
-        if (!fast_cols_fwd_dispatch(g.M, g.fast_cols.T, false, run)) return -8;
+        if (!run_fast_cols_fwd(g.M, g.fast_cols.T, false, run)) return -8;
     } else {
         ColsR2CArgs ia = image_cols_args(g, t, d, data, S);
         for (int plane = 0; plane < F; plane++)
@@ -188,7 +58,7 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
         d.fr_tw2 = t.fr.tw2.data();
         FastRowsFwdArgs fa = fast_rows_fwd_args(g, d, S);
         EmuFastRowsFwd run{fa, lds.data(), F * g.rows};
-        if (!fast_rows_fwd_dispatch(g.Lw, run)) return -9;
+        if (!run_fast_rows_fwd(g.Lw, run)) return -9;
         return 0;
     }
     RowsFwdArgs ra = image_rows_args(g, t, d, S);
@@ -221,7 +91,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             FastColsFwdArgs fa = fast_cols_fwd_args(g, d, kernels[k], (size_t)kh[k] * kw[k], kh[k], kh[k], kw[k], F, A.data(),
                                                     (size_t)g.rows * a_pitch_for(kw[k]), a_pitch_for(kw[k]));
             EmuFastColsFwd run{fa, lds.data(), 2};
-            if (!fast_cols_fwd_dispatch(g.M, g.fast_cols.T, fast_cols_fwd_pruned_ok(g.fast_cols, kh[k]), run)) return -8;
+            if (!run_fast_cols_fwd(g.M, g.fast_cols.T, fast_cols_fwd_pruned_ok(g.fast_cols, kh[k]), run)) return -8;
         } else {
             ColsR2CArgs ka = kernel_cols_args(g, t, d, kernels[k], kh[k], kw[k], A.data());
             for (int plane = 0; plane < F; plane++)
@@ -234,7 +104,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fr_tw2 = t.fr.tw2.data();
             FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
             EmuFastRows run{fa, lds.data(), g.rows, (g.rows_multi_ok() && g.rows_group > 1) ? g.rows_group : 0};
-            if (!fast_rows_dispatch(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
+            if (!run_fast_rows(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;
         } else {
             SpectralRowsArgs sa = spectral_rows_args(g, t, d, A.data(), kw[k], S, Y.data());
             for (int r = 0; r < g.rows; r++) spectral_rows_body(ctx, lds.data(), sa, r, 0);
@@ -246,7 +116,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fc_rowoff = t.fcl.rowoff.data();
             FastColsArgs fa = fast_cols_args(g, d, Y.data(), out[k], 0, 1);
             EmuFastCols run{fa, lds.data(), 3};   // 3 persistent workgroups share the tiles
-            if (!fast_cols_dispatch(g.M, g.fast_cols.T, run)) return -6;
+            if (!run_fast_cols(g.M, g.fast_cols.T, run)) return -6;
         } else {
             ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
             for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
@@ -291,6 +161,8 @@ int emu_fft1d(int L, const float* xin /* 2L floats */, float* xout /* 2L floats 
 // path mode (0 generic kernels only, 1 specialised + row-major intermediate, 2 default) and maps per
 // workgroup of the multi-map row kernel (-1 auto) of the plans emulated from here on
 void emu_set_tuning(int path_mode, int rows_group) { g_tune.path_mode = path_mode; g_tune.rows_group = rows_group; }
+// 1: the emulated plans transform the ceil16 window itself (fftconv_plan_options.exact_window)
+void emu_set_exact_window(int on) { g_tune.exact_window = on != 0; }
 void emu_allow_fast(int mode) { g_tune.path_mode = mode; }
 // 1 if a plan of these sizes would use the fast spectral-row kernel
 int emu_uses_fast_rows(int H, int W, int F, int max_kh, int max_kw) {

@@ -28,7 +28,13 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 (24, 6000, 1, 3, 100, 1), (6000, 40, 2, 90, 9, 1),      # 6144 in one dimension each
                 # both kernels specialised with the 4-column output tiles (M = 3072 / 4224) and a short
                 # row transform: the pair-adjacent intermediate + merge-while-landing path of those tiles
-                (6000, 250, 1, 60, 31, 2), (8192, 260, 1, 127, 20, 1)]
+                (6000, 250, 1, 60, 31, 2), (8192, 260, 1, 127, 20, 1),
+                # round 4: the lengths that close the gaps of the ladder, one dimension each (rows / columns)
+                (24, 1300, 1, 5, 40, 1), (1300, 40, 2, 30, 9, 1),       # 1344
+                (20, 1700, 2, 5, 50, 1), (1700, 40, 1, 50, 9, 2),       # 1760
+                (16, 2500, 1, 3, 60, 1), (2500, 28, 1, 50, 5, 1),       # 2560
+                (12, 3400, 1, 3, 100, 1), (3400, 28, 1, 100, 5, 1),     # 3520
+                (10, 5000, 1, 3, 110, 1), (5000, 30, 1, 110, 3, 1)]     # 5120
 # (path_mode, rows_group): path mode 0 generic kernels, 1 specialised kernels + row-major
 # intermediate, 2 (default) specialised kernels + tiled pair-adjacent intermediate; rows_group -1 auto
 VARIANTS = [(0, -1), (1, -1), (2, -1), (2, 0), (2, 3)]
@@ -144,6 +150,35 @@ def test_emulated_multi_map_row_kernel(emu, oracle, tuned, shape):
         assert util.rel_err(g, r) < 1e-5
 
 
+# the BASELINE windows that are awkward to factor have kernels of their own (1088 = 2^6 x 17: cfg2; 4160 = 2^6 x 5 x 13:
+# cfg4); plans that must transform the window itself (exact_window: the spectrum exchange in the reference's order,
+# src/cudaFFTData.cu:90-103, src/cudaConvFFTData.cu:92-98) run on them
+NATIVE_SHAPES = [(1024, 40, 1, 63, 9, 2), (40, 1024, 2, 9, 63, 1), (1024, 1024, 1, 63, 63, 1), (1030, 1025, 1, 57, 64, 2),
+                 (4096, 28, 1, 63, 5, 1), (24, 4096, 1, 5, 63, 2), (20, 4040, 2, 3, 120, 1)]
+
+
+@pytest.mark.parametrize("shape", NATIVE_SHAPES)
+@pytest.mark.parametrize("variant", [(2, -1), (1, -1), (2, 3)])
+def test_emulated_native_window_kernels(emu, oracle, tuned, shape, variant):
+    tuned(variant)
+    emu.emu_set_exact_window(1)
+    try:
+        H, W, F, kh, kw, n = shape
+        lh, lw = ctypes.c_int(0), ctypes.c_int(0)
+        assert emu.emu_plan_lengths(H, W, F, kh, kw, ctypes.byref(lh), ctypes.byref(lw)) == 0
+        assert (lh.value, lw.value) == (util.ceil16(H + kh - 1), util.ceil16(W + kw - 1))
+        assert emu.emu_uses_fast_rows(H, W, F, kh, kw) > 0         # no generic kernel in the dimension(s) at 1088 / 4160
+        if min(H, W) > 1000:
+            assert emu.emu_uses_fast_rows(H, W, F, kh, kw) == 3
+        data, ks = make_inputs(shape, 61)
+        rc, got = emu_conv(emu, data, kh, kw, ks)
+        assert rc == 0
+        for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+            assert util.rel_err(g, r) < 1e-5
+    finally:
+        emu.emu_set_exact_window(0)
+
+
 def test_fast_row_kernel_rejects_too_wide_kernels(emu):
     # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224); plans for
     # wider MAX_KERNEL_W fall back to the generic kernel at plan time
@@ -246,14 +281,14 @@ def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle):
         assert util.rel_err(got[i], r) < 1e-5
 
 
-def _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, expect_transform, sample):
+def _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, expect_transform, sample, exact_window=0):
     """device-resident maps of the specialised path (default) against the generic kernels
     (kernel_path 1) on the same inputs"""
     torch = pytest.importorskip("torch")
     kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(x, (2, 1, 0)) for x in ks]))).cuda()
     maps = {}
     for mode in (2, 0):
-        with fftconv.Plan(H, W, 1, kh, kw, options=plan_options((mode, -1))) as p:
+        with fftconv.Plan(H, W, 1, kh, kw, options=dict(plan_options((mode, -1)), exact_window=exact_window)) as p:
             if mode == 2:
                 assert expect_transform(p.info.transform_h, p.info.transform_w)
             p.set_image(data)
@@ -282,8 +317,39 @@ def test_gpu_big_square_walk_with_remainder(fftconv, size, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", NATIVE_SHAPES)
+@pytest.mark.parametrize("group", [-1, 3])
+def test_gpu_native_window_kernels(fftconv, oracle, shape, group):
+    """exact_window plans at the cfg2 / cfg4 windows (1088, 4160) run on those lengths' own kernels"""
+    H, W, F, kh, kw, n = shape
+    data, ks = make_inputs(shape, 67)
+    with fftconv.Plan(H, W, F, kh, kw, options=dict(plan_options((2, group)), exact_window=1)) as p:
+        assert p.info.exact_window == 1 and p.get_option("specialised_kernels") > 0
+        if min(H, W) > 1000:
+            assert p.get_option("specialised_kernels") == 3
+        p.set_image(data)
+        got = p.convolve(ks)
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lh,lw", [(1088, 1088), (1088, 4160), (4160, 1088)])
+def test_gpu_native_window_pairs_vs_generic(fftconv, lh, lw):
+    kh, kw = 33, 47
+    H, W = lh - kh + 1 - 3, lw - kw + 1 - 5
+    n = 17
+    rng = np.random.default_rng(lh * 10007 + lw)
+    data = rng.standard_normal((H, W, 1)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, 1)).astype(np.float32) for _ in range(n)]
+    _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, lambda a, b: (a, b) == (lh, lw), range(n), exact_window=1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lh,lw", [(288, 288), (576, 768), (768, 576), (1152, 1536), (1536, 1152), (2112, 3072), (3072, 2112),
-                                   (4224, 576), (768, 4224), (6144, 288), (288, 6144), (8448, 768), (1536, 8448), (2112, 2112)])
+                                   (4224, 576), (768, 4224), (6144, 288), (288, 6144), (8448, 768), (1536, 8448), (2112, 2112),
+                                   # round 4's lengths
+                                   (1344, 1760), (1760, 1344), (2560, 3520), (3520, 2560), (5120, 1344), (1344, 5120), (5120, 5120)])
 def test_gpu_every_fast_length_pair_vs_generic(fftconv, lh, lw):
     """both kernels specialised, every transform length at least once along h and along w, 17
     kernels (multi-map walk + remainder), odd data sizes: specialised path against the generic

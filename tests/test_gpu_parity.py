@@ -789,7 +789,9 @@ def test_output_region_rejects_empty_and_unknown(fc):
 @pytest.mark.parametrize("shape", [
     (64, 8, 5, 10, 4),          # the demo problem: generic kernels
     (256, 256, 1, 31, 31),      # cfg1: 288 x 288, both specialised kernels (register-order spectrum rows)
-    (1024, 1024, 1, 63, 63),    # cfg2's 1088 window: exact_window keeps the transform off 1152
+    (1024, 1024, 1, 63, 63),    # cfg2's 1088 window: exact_window keeps the transform off 1152 -- on the 1088-point kernels (round 4)
+    (4096, 1024, 1, 63, 63),    # cfg4's 4160 window along h (M = 2080 kernels), 1088 along w
+    (600, 4096, 2, 40, 63),     # 4160 along w (row kernel), F = 2
     (500, 4096, 2, 40, 127),    # 4224 along w only, F = 2
     (300, 200, 3, 21, 9),
 ])
@@ -807,6 +809,10 @@ def test_spectrum_export_import_in_reference_order(fc, oracle, shape):
     want = np.fft.rfft2(padded, axes=(1, 2))
     with fc.Plan(H, W, F, kh, kw, options={"exact_window": 1}) as p:
         assert p.info.exact_window == 1 and (p.info.transform_h, p.info.transform_w) == (fh, fw)
+        if (fh, fw) in ((1088, 1088), (4160, 1088)):       # the BASELINE windows of cfg2 / cfg4: no generic kernel runs
+            assert p.get_option("specialised_kernels") == 3
+        if fw == 4160:
+            assert p.get_option("specialised_kernels") & 1
         p.set_image(data)
         spec = p.export_spectrum()
         assert spec.shape == (F, fw, fh // 2 + 1)
@@ -893,10 +899,12 @@ def test_full_size_five_feature_maps_vs_oracle(fc, oracle):
         assert abs(float(g.astype(np.float64).sum()) - want) / abs(want) < 1e-5
 
 
-def test_deferred_kernel_preparation_in_every_order(fc, oracle):
-    """fftconv_plan_prepare_kernels_packed only records the request; the kernels' column pass runs in ONE launch
-    with the next image's column pass (set_image on the same stream) or, if none comes, at the convolve.  Every
-    order of the calls must give the maps of a plan that never prepared anything."""
+@pytest.mark.parametrize("defer", [1, 0])
+def test_deferred_kernel_preparation_in_every_order(fc, oracle, defer):
+    """With plan option defer_prepare fftconv_plan_prepare_kernels_packed only records the request; the kernels' column
+    pass runs in ONE launch with the next image's column pass (set_image on the same stream) or, if none comes, at the
+    convolve.  Without it (the default) the pass is queued at once -- ahead of whatever the caller waits for next, the
+    overlap the call exists for.  Every order of the calls must give the maps of a plan that never prepared anything."""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda", 0)
     for (H, W, F, kh, kw, n) in [(256, 256, 1, 31, 31, 3), (300, 260, 2, 15, 13, 5), (1024, 1024, 1, 63, 63, 4)]:
@@ -916,9 +924,17 @@ def test_deferred_kernel_preparation_in_every_order(fc, oracle):
                 for j, r in enumerate(want):
                     assert util.rel_err(out[j].cpu().numpy().T, r) < TIGHT, (H, W, j)
 
+            assert p.get_option("defer_prepare") == 0          # the default: launched at once
+            p.set_option("defer_prepare", defer)
             # prepare -> set_image (merged launch) -> convolve
             p.prepare_kernels_packed_device(n, k_d.data_ptr(), kh, kw)
+            # deferred: recorded, nothing queued yet; default: already on the stream (nothing pending)
+            if not defer:
+                assert p.get_option("prepare_pending") == 0
+            elif (H, W) in ((256, 256), (1024, 1024)):       # lengths with a specialised column pass: the request waits
+                assert p.get_option("prepare_pending") == 1
             p.set_image_device(img_d.data_ptr())
+            assert p.get_option("prepare_pending") == 0
             p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
             check(ref)
             # prepare -> convolve (no image in between: flushed by the convolve), image spectrum reused
@@ -953,3 +969,111 @@ def test_deferred_kernel_preparation_in_every_order(fc, oracle):
             prof = p.profile(reset=True)
             assert prof["kernel_cols"]["launches"] == 1 and prof["image_cols"]["launches"] == 1
             p.set_option("profile", 0)
+
+
+def test_one_shot_plan_cache(fc, oracle):
+    """fftconv_convolution_fft keeps the plans of its last few problems (the reference rebuilds its cuFFT plans and
+    buffers in every call, src/cudaConvolutionFFT.cu:127-185,302-310): a second call with ANOTHER image and OTHER
+    kernels of the same problem size takes the cached plan and still matches the oracle; an argument error leaves the
+    cache usable; the limits and fftconv_cache_clear release plans."""
+    fc.cache_clear()
+    fc.cache_configure(4)
+    s0 = fc.cache_stats()
+    H, W, F, kh, kw, n = 200, 176, 2, 15, 9, 3
+    img, ks = util.synth(501, H, W, F, kh, kw, n)
+    got = fc.cudaConvolutionFFT(img, kh, kw, ks)
+    t1 = fc.last_call_timing()
+    assert t1["cache_hit"] == 0 and t1["total_ms"] > 0
+    for g, r in zip(got, oracle.conv_fft(img, kh, kw, ks)):
+        assert util.rel_err(g, r) < TOL
+    s1 = fc.cache_stats()
+    assert s1["plans"] == s0["plans"] + 1 and s1["misses"] == s0["misses"] + 1 and s1["device_bytes"] > 0
+    # same problem size, different image, different kernels (also smaller ones, ragged): cached plan
+    img2, ks2 = util.synth(502, H, W, F, kh, kw, n + 2)
+    ks2[1] = ks2[1][:7, :5, :].copy()
+    got2 = fc.cudaConvolutionFFT(img2, kh, kw, ks2)
+    t2 = fc.last_call_timing()
+    assert t2["cache_hit"] == 1
+    for g, r in zip(got2, oracle.conv_fft(img2, kh, kw, ks2)):
+        assert util.rel_err(g, r) < TOL
+    s2 = fc.cache_stats()
+    assert s2["plans"] == s1["plans"] and s2["hits"] == s1["hits"] + 1
+    # an argument error on the cached plan (feature mismatch; a kernel larger than the window): the cache stays usable
+    bad = [k[:, :, :1].copy() for k in ks]
+    with pytest.raises(fc.FFTConvError) as ei:
+        fc.cudaConvolutionFFT(img, kh, kw, bad)
+    assert ei.value.status == -3
+    with pytest.raises(fc.FFTConvError):
+        fc.cudaConvolutionFFT(img, kh, kw, [np.zeros((H + 100, 3, F), dtype=np.float32)])
+    assert fc.cache_stats()["plans"] == s1["plans"]
+    got3 = fc.cudaConvolutionFFT(img, kh, kw, ks)
+    assert fc.last_call_timing()["cache_hit"] == 1
+    for g, r in zip(got3, oracle.conv_fft(img, kh, kw, ks)):
+        assert util.rel_err(g, r) < TOL
+    # different options are different plans; generic kernels give the same maps
+    got4 = fc.cudaConvolutionFFT(img, kh, kw, ks, options={"kernel_path": 1})
+    assert fc.last_call_timing()["cache_hit"] == 0
+    for g, r in zip(got4, got3):
+        assert util.rel_err(g, r) < TIGHT
+    # the limit evicts the least recently used plan
+    fc.cache_configure(2)
+    assert fc.cache_stats()["plans"] <= 2
+    for hh in (64, 80, 96):
+        i3, k3 = util.synth(600 + hh, hh, 48, 1, 5, 5, 1)
+        fc.cudaConvolutionFFT(i3, 5, 5, k3)
+    assert fc.cache_stats()["plans"] == 2
+    i3, k3 = util.synth(696, 96, 48, 1, 5, 5, 1)
+    fc.cudaConvolutionFFT(i3, 5, 5, k3)
+    assert fc.last_call_timing()["cache_hit"] == 1          # the most recent one is still there
+    i3, k3 = util.synth(664, 64, 48, 1, 5, 5, 1)
+    fc.cudaConvolutionFFT(i3, 5, 5, k3)
+    assert fc.last_call_timing()["cache_hit"] == 0          # the oldest was pushed out
+    # off: every call builds and tears down its plan, as the reference does
+    fc.cache_configure(0)
+    assert fc.cache_stats()["plans"] == 0
+    got5 = fc.cudaConvolutionFFT(img, kh, kw, ks)
+    assert fc.last_call_timing()["cache_hit"] == 0 and fc.cache_stats()["plans"] == 0
+    for g, r in zip(got5, got3):
+        assert np.array_equal(g, r)
+    fc.cache_configure(4)
+    fc.cudaConvolutionFFT(img, kh, kw, ks)
+    assert fc.cache_stats()["plans"] == 1
+    fc.cache_clear()
+    assert fc.cache_stats()["plans"] == 0 and fc.cache_stats()["device_bytes"] == 0
+
+
+def test_one_shot_plan_cache_blockwise_and_threads(fc, oracle):
+    """Block-wise plans are cached like any other; two threads calling the one-shot entry with the same problem at the
+    same time never share a plan (the second builds its own)."""
+    import threading
+    fc.cache_clear()
+    fc.cache_configure(4)
+    H, W, F, kh, kw, n = 150, 130, 1, 9, 9, 2
+    img, ks = util.synth(701, H, W, F, kh, kw, n)
+    ref = oracle.conv_fft(img, kh, kw, ks)
+    for rep in range(2):
+        got = fc.cudaConvolutionFFT(img, kh, kw, ks, options={"max_transform": 64})
+        assert fc.last_call_timing()["cache_hit"] == rep
+        for g, r in zip(got, ref):
+            assert util.rel_err(g, r) < TOL
+    res, errs = {}, []
+
+    def work(i):
+        try:
+            im, kk = util.synth(800 + i, H, W, F, kh, kw, n)
+            for _ in range(3):
+                res[i] = (im, kk, fc.cudaConvolutionFFT(im, kh, kw, kk))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i, (im, kk, got) in res.items():
+        for g, r in zip(got, oracle.conv_fft(im, kh, kw, kk)):
+            assert util.rel_err(g, r) < TOL
+    assert 1 <= fc.cache_stats()["plans"] <= 4
+    fc.cache_clear()

@@ -263,7 +263,8 @@ def test_gpuarray_kernels_and_released_handles(mex, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4), (256, 256, 1, 31, 31), (200, 150, 2, 9, 12)])
+@pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4), (256, 256, 1, 31, 31), (200, 150, 2, 9, 12),
+                                   (1024, 1024, 1, 63, 63)])      # cfg2: the 1088 x 1088 window on its own specialised kernels
 def test_two_step_gateways_speak_the_reference_gpuarray_protocol(mex, oracle, shape):
     """fftData = cudaFFTData(data, kH, kW) is a complex single gpuArray of (FFT_H/2+1) x FFT_W x F holding
     cuFFT's R2C output (src/cudaFFTData.cu:90-103,150) == numpy.fft.rfft2 of the zero-padded planes;
