@@ -57,7 +57,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride + (MULTIF ? (size_t)f * g.a_feat_stride : 0);
         static_for<0, C::RND1>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            const int u = t + NT * r;
+            int u = t + NT * r;
+            if constexpr (MULTIF) FC_OPAQUE(u);   // F > 1: index arithmetic recomputed per step, not hoisted out of the walk and spilled
             const int rr = u / C::NB1, j = u - rr * C::NB1;
             const int row = row0 + rr;
             st.x[r] = (rr < RPW && row < rows && j < kw) ? abase[(size_t)row * g.a_pitch + j] : mk(0.f, 0.f);
@@ -109,7 +110,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         if (!FOLD || m == 0 || f > 0) ctx.phase([&](int t, State& st) {
             static_for<0, C::RND1>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                const int u = t + NT * r;
+                int u = t + NT * r;
+                if constexpr (MULTIF) FC_OPAQUE(u);
                 const int rr = u / C::NB1, j = u - rr * C::NB1;
                 if (rr < RPW && j < kw) {
                     c32* buf = lds + rr * L;
@@ -133,7 +135,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         ctx.phase([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                const int u = t + NT * r;
+                int u = t + NT * r;
+                if constexpr (MULTIF) FC_OPAQUE(u);
                 const int rr = u / C::NB2, w = u - rr * C::NB2;
                 if (rr < RPW) {
                     const int c1 = w / R3, b = w - c1 * R3;
@@ -157,7 +160,9 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         FC_ROWS_STAMP(2);
         // P3: forward stage 3, product with the image spectrum (registers), inverse stage 3
         const bool last_f = (f == nF - 1);
-        ctx.phase([&](int t, State& st) {
+        ctx.phase([&](int t_, State& st) {
+            int t = t_;
+            if constexpr (MULTIF) FC_OPAQUE(t);
             const int rr = t / C::NB3, q = t - rr * C::NB3;
             if (rr < RPW) {
                 // MULTIF: this feature's image-spectrum row.  Only its first FC_MULTIF_S_EARLY register pairs are requested
@@ -166,7 +171,10 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 // sum, the kernel spilled 27-50 registers at L = 4224, differently in every translation unit, and a
                 // scratch reload shares the in-order memory counter with these very loads (59.7 -> 56.6 us per map at
                 // F = 4 with none early and no spills, profiles/r03i_f4_image_row_load_placement.txt)
-                constexpr int S_EARLY = (FC_MULTIF_S_EARLY < R3 / 2) ? FC_MULTIF_S_EARLY : R3 / 2;
+                // (configurations with several rows per workgroup or a stage 3 above radix 22 keep more per-thread state:
+                //  nothing early there)
+                constexpr int S_EARLY_CFG = (RPW > 1 || R3 > 22) ? 0 : FC_MULTIF_S_EARLY;
+                constexpr int S_EARLY = (S_EARLY_CFG < R3 / 2) ? S_EARLY_CFG : R3 / 2;
                 if constexpr (MULTIF && (0) < (S_EARLY)) {
                     if (row0 + rr < rows) {
                         const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(row0 + rr) * g.s_pitch;
@@ -259,7 +267,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
         ctx.phase([&](int t, State&) {
             static_for<0, C::RND2>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                const int u = t + NT * r;
+                int u = t + NT * r;
+                if constexpr (MULTIF) FC_OPAQUE(u);
                 const int rr = u / C::NB2, w = u - rr * C::NB2;
                 if (rr < RPW) {
                     const int c1 = w / R3, b = w - c1 * R3;

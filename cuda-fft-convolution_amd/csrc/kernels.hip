@@ -166,8 +166,11 @@ hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipSt
     return e;
 }
 
+hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s);
+
 hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s) {
     if (rows <= 0 || kernels <= 0) return hipSuccess;
+    if (a.F > 1) return launch_fast_rows_multi(L, nz2, a, rows, kernels, 1, s);   // one map per workgroup of the (map, feature) walk
     bool m = false;
     hipError_t e = launch_fast_rows_g0(L, nz2, a, rows, kernels, order, s, &m);
     if (!m) e = launch_fast_rows_g1(L, nz2, a, rows, kernels, order, s, &m);

@@ -49,7 +49,8 @@ struct EmuFastRows {
                      // the prefetch slot and the LDS reuse are exercised, the indexing is not
     template <class Cfg, int NZ2>
     void go() {
-        if (group > 1) {
+        if (group > 1 || a.F > 1) {      // (F > 1: always the walk over (map, feature) pairs, as the product's launchers)
+            const int group = this->group > 1 ? this->group : 1;
             FastRowsArgs b = a;
             b.a_kernel_stride = 0;
             b.y_kernel_stride = 0;
@@ -73,13 +74,8 @@ struct EmuFastRows {
         for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
             // poison the LDS image so that reads of never-written cells show up
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            if (a.F > 1) {
-                HostPhaseCtx<RowState<Cfg, true>> ctx(Cfg::NT);
-                fast_rows_body<Cfg, NZ2, true>(ctx, lds, a, grp, 0, rows);
-            } else {
-                HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
-                fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, grp, 0, rows);
-            }
+            HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
+            fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, grp, 0, rows);
         }
     }
 };
