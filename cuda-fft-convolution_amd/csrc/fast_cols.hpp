@@ -106,6 +106,7 @@ struct ColPairState {
 template <class C, bool TILED, bool SLICED = false, class Ctx>
 FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
     static_assert(!SLICED || TILED, "column slices exist for the tiled intermediate only");
+    static_assert(!SLICED || (C::T & (C::T - 1)) == 0, "column slices: the tile width must be a power of two (slices of whole column pairs)");
     constexpr bool PLAND = TILED;
     constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
     constexpr int T2 = T / 2;

@@ -328,12 +328,14 @@ constexpr int FC_SLICE_MAX_M = 1056;
 inline bool fast_cols_slice_plan(int M, int T, int want, FastColsArgs& a, int& grid) {
     a.tail_first = a.tail_tiles = a.slice_shift = 0;
     if (!a.y_tiled || M > FC_SLICE_MAX_M || want < 2 || a.ntiles <= 0) return false;
+    if (T & (T - 1)) return false;        // slices are power-of-two fractions of a tile ...
     const int full_rounds = a.ntiles / want, rem = a.ntiles - full_rounds * want;
     // (launches of less than one round stay whole: cfg1's 18 tiles as 144 two-column slices took 24.6 instead of 22.3 us
     //  per step -- every slice pays the tile's whole phase latency)
     if (rem == 0 || full_rounds == 0) return false;
     int shift = 0;
-    while ((2 << shift) * rem <= want && (T >> (shift + 1)) >= 2) shift++;
+    // ... of an EVEN number of columns: the gather and the landing work on column pairs (fast_cols.hpp)
+    while ((2 << shift) * rem <= want && (T >> (shift + 1)) >= 2 && ((T >> (shift + 1)) & 1) == 0) shift++;
     if (shift == 0) return false;
     a.tail_first = full_rounds * want;
     a.tail_tiles = rem;

@@ -165,6 +165,12 @@ struct HostRing {
         const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + 4095) & ~(uintptr_t)4095;
         const uintptr_t b = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(uintptr_t)4095;
         if (b > a) {
+#ifdef MADV_HUGEPAGE
+            // fresh destinations of many megabytes (what mxCreateNumericArray hands out): let the kernel back them with 2-MB
+            // pages where it may -- one fault and one clear per 2 MB instead of 512 (cfg3, 64 fresh maps: the page clearing was
+            // 4/5 of the call); a no-op for resident pages and where transparent huge pages are off
+            if (b - a >= ((size_t)4 << 20)) (void)madvise(reinterpret_cast<void*>(a), b - a, MADV_HUGEPAGE);
+#endif
             (void)madvise(reinterpret_cast<void*>(a), b - a, MADV_POPULATE_WRITE);
         }
 #else
@@ -514,8 +520,10 @@ int ring_ensure(fftconv_plan* p) {
     chunk = std::min(chunk, (map_bytes + 4095) / 4096 * 4096);
     chunk = std::max<size_t>(4096, chunk / 4096 * 4096);
     const bool use_ring = p->opt_host_stream == 2;
+    // (direct copies: the threads also pre-fault fresh destination pages, which is CPU work -- up to 8 of them for big maps)
+    const unsigned direct_threads = map_bytes >= ((size_t)8 << 20) ? 8u : 4u;
     int nthreads = p->opt_host_threads > 0 ? (int)p->opt_host_threads
-                   : (int)std::max(1u, std::min(use_ring ? 6u : 4u, std::thread::hardware_concurrency() / 2));
+                   : (int)std::max(1u, std::min(use_ring ? 6u : direct_threads, std::thread::hardware_concurrency() / 2));
     int nslots = !use_ring ? 0 : p->opt_host_slots > 0 ? (int)p->opt_host_slots : std::max(8, 2 * nthreads + 2);
     HostRing* r = new (std::nothrow) HostRing();
     if (!r) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
@@ -895,6 +903,7 @@ struct TiledState {
     DevBuf<c32> specs;               // block spectra, [block][spec_elems] (own buffer)
     c32* specs_x = nullptr;          // caller-owned instead (fftconv_plan_use_spectrum_buffer)
     DevBuf<float> big, tmp, blk;     // full maps of a kernel chunk, block maps of that chunk, one zero-padded image block
+    DevBuf<float> kstage;            // host kernels of a chunk, staged on the device once (every block convolves them)
     std::vector<float> hblk;         // host staging of one image block
     bool have_image = false;
     c32* spec_base() const { return specs_x ? specs_x : specs.p; }
@@ -903,7 +912,7 @@ struct TiledState {
     void release() {
         if (sub) fftconv_plan_destroy(sub);
         sub = nullptr;
-        specs.release(); big.release(); tmp.release(); blk.release();
+        specs.release(); big.release(); tmp.release(); blk.release(); kstage.release();
     }
 };
 
@@ -992,6 +1001,7 @@ int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const in
     if (!ts->have_image) return fail(FFTCONV_ERR_NO_IMAGE, "no image spectrum: call fftconv_plan_set_image first");
     for (int k = 0; k < n; k++) {
         if (!kernels[k]) return fail(FFTCONV_ERR_INVALID_ARG, "kernel %d is NULL", k);
+        if (!out_packed && !out[k]) return fail(FFTCONV_ERR_INVALID_ARG, "output %d is NULL", k);   // everything checked before anything is queued
         if (kh[k] < 1 || kw[k] < 1 || kh[k] > ts->FH || kw[k] > ts->FW)      // src/cudaConvolutionFFT.cu:242
             return fail(FFTCONV_ERR_KERNEL_SHAPE,
                         "Kernel and Data must have the same number of features and kernel size should be smaller than data size");
@@ -1010,18 +1020,37 @@ int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const in
     for (int k0 = 0; k0 < n; k0 += nc) {
         const int nk = std::min(nc, n - k0);
         float* big = out_packed ? out_packed + (size_t)k0 * big_map : ts->big.p;
+        // host (or mixed) kernels: on the device once per chunk, not once per block (every block convolves the same kernels)
+        const float* const* kptr = kernels + k0;
+        int kloc = kernel_location;
+        std::vector<const float*> staged;
+        if (kernel_location != FFTCONV_DEVICE && ts->nblk > 1) {
+            size_t total = 0;
+            for (int j = 0; j < nk; j++) total += (size_t)ts->F * kh[k0 + j] * kw[k0 + j];
+            if (int rc = ts->kstage.ensure(total)) return rc;
+            staged.resize(nk);
+            size_t off = 0;
+            for (int j = 0; j < nk; j++) {
+                const size_t per = (size_t)ts->F * kh[k0 + j] * kw[k0 + j];
+                HIP_TRY(hipMemcpyAsync(ts->kstage.p + off, kernels[k0 + j], per * sizeof(float),
+                                       kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice : hipMemcpyDefault, sub->stream));
+                staged[j] = ts->kstage.p + off;
+                off += per;
+            }
+            kptr = staged.data();
+            kloc = FFTCONV_DEVICE;
+        }
         HIP_TRY(hipMemsetAsync(big, 0, big_map * nk * sizeof(float), sub->stream));
         for (int b = 0; b < ts->nblk; b++) {
             const int y0 = (b % ts->nbh) * ts->Bh, x0 = (b / ts->nbh) * ts->Bw;
             if (int rc = fftconv_plan_use_spectrum_buffer(sub, ts->spec_base() + (size_t)b * ts->spec_elems, ts->spec_elems * sizeof(c32))) return rc;
             if (int rc = fftconv_plan_mark_spectrum_valid(sub)) return rc;
-            if (int rc = fftconv_plan_convolve(sub, nk, kernels + k0, kh + k0, kw + k0, kernel_location, tptr.data(), FFTCONV_DEVICE)) return rc;
+            if (int rc = fftconv_plan_convolve(sub, nk, kptr, kh + k0, kw + k0, kloc, tptr.data(), FFTCONV_DEVICE)) return rc;
             hipError_t e = launch_add_window(big, ts->FH, ts->FW, big_map, y0, x0, ts->tmp.p, sub->g.fft_h, sub->g.fft_w, blk_map, nk, sub->stream);
             if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "overlap-add failed: %s", hipGetErrorString(e));
         }
         if (!out_packed) {
             for (int j = 0; j < nk; j++) {
-                if (!out[k0 + j]) return fail(FFTCONV_ERR_INVALID_ARG, "output %d is NULL", k0 + j);
                 HIP_TRY(hipMemcpyAsync(out[k0 + j], big + (size_t)j * big_map, big_map * sizeof(float),
                                        out_location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sub->stream));
             }
@@ -1514,7 +1543,13 @@ int fftconv_plan_convolve_packed(fftconv_plan* plan, int n_kernel, const float* 
         std::vector<const float*> kp(n_kernel);
         std::vector<int> khs(n_kernel, kernel_h), kws(n_kernel, kernel_w);
         for (int j = 0; j < n_kernel; j++) kp[j] = kernels_device + per * j;
-        return tiled_convolve(plan, n_kernel, kp.data(), khs.data(), kws.data(), FFTCONV_DEVICE, nullptr, FFTCONV_DEVICE, out_device);
+        const int rc = tiled_convolve(plan, n_kernel, kp.data(), khs.data(), kws.data(), FFTCONV_DEVICE, nullptr, FFTCONV_DEVICE, out_device);
+        if (rc) {     // as fftconv_plan_convolve: nothing of a failed call may still be running when the error is returned
+            const std::string keep = g_last_error;
+            (void)hipStreamSynchronize(plan->tiled->sub->stream);
+            g_last_error = keep;
+        }
+        return rc;
     }
     Sink sink;
     sink.packed = out_device;

@@ -52,9 +52,17 @@ RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // An RCCL the process has ALREADY mapped comes first (a PyTorch process has its own bundled librccl in: loading the
+        // system's copy beside it would put a second, different RCCL runtime into the process); only then the search path.
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* name : names) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (api.handle) break;
+        }
+        if (!api.handle && dlsym(RTLD_DEFAULT, "ncclCommInitAll")) api.handle = dlopen(nullptr, RTLD_NOW);   // mapped under another name
+        for (const char* name : names) {
+            if (api.handle) break;
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!api.handle) return;
         auto sym = [&](const char* n) { return dlsym(api.handle, n); };
@@ -65,6 +73,10 @@ RcclApi& rccl() {
         api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         api.ok = api.CommInitAll && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Broadcast;
+        // the prototypes and the ncclInt8 = 0 used here are those of NCCL / RCCL 2.x: refuse anything else
+        auto get_version = reinterpret_cast<int (*)(int*)>(sym("ncclGetVersion"));
+        int version = 0;
+        if (!get_version || get_version(&version) != 0 || version < 20000 || version >= 30000) api.ok = false;
     });
     return api;
 }

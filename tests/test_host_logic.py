@@ -334,7 +334,8 @@ def test_hot_kernels_do_not_spill():
     F > 1 walk (k_fast_rows_multi_f: feature sum + image row + butterfly do not fit 168 registers) stays within the
     documented bound."""
     rep = _resource_reports()
-    assert rep, "no resource reports: build the library first"
+    if not rep:
+        pytest.skip("no csrc/*.rpt resource reports beside the objects (a library built without csrc/Makefile)")
     hot = {k: v for k, v in rep.items() if any(s in k for s in ("k_fast_rows_multiI", "k_fast_colsI", "k_fast_cols_fwdI", "k_fast_rows_fwdI"))}
     assert len(hot) > 40, len(hot)
     bad = {k: v for k, v in hot.items() if v.get("spill", 0) != 0 or v.get("scratch", 0) != 0 or v.get("occ", 0) < 3}
@@ -344,11 +345,10 @@ def test_hot_kernels_do_not_spill():
     bad = {k: v for k, v in bad.items() if k not in known}
     assert not bad, bad
     multi_f = {k: v for k, v in rep.items() if "k_fast_rows_multi_fI" in k}
-    assert multi_f and all(v["occ"] >= 3 for v in multi_f.values())
-    # the cfg3-sized transform (4224 = 8.24.22) of the F > 1 walk: spill-free since round 3 (only part of the image-spectrum row
-    # is requested ahead of the radix-22 butterfly); configurations with two or four rows per workgroup still spill, under 64
-    l4224 = {k: v["spill"] for k, v in multi_f.items() if "Li4224ELi8ELi24ELi22ELi192ELi1E" in k}
-    linear = [v for k, v in l4224.items() if "ELb1EEEv" in k]       # the LINEAR store form: what a default plan launches
-    assert len(linear) == 3 and max(linear) == 0, l4224
-    assert max(l4224.values()) <= 16, l4224
-    assert max(v["spill"] for v in multi_f.values()) <= 64
+    assert len(multi_f) >= 40 and all(v["occ"] >= 3 for v in multi_f.values())
+    # Round 4: EVERY configuration of the F > 1 walk is spill-free (rounds 2-3: 19-48 spilled registers in the configurations with
+    # two or four rows per workgroup -- what went to scratch were per-thread index computations hoisted out of the walk; they
+    # are now recomputed per step, FC_OPAQUE in fast_rows_multi.hpp), and the one-map F > 1 kernel (22-68) is not built any more
+    spilled = {k: v for k, v in multi_f.items() if v.get("spill", 0) or v.get("scratch", 0)}
+    assert not spilled, spilled
+    assert not [k for k in rep if "k_fast_rowsI" in k and k.endswith("ELb1EEEvNS_12FastRowsArgsEiiii")]
