@@ -843,8 +843,10 @@ def main():
                        "transform": [info.transform_h, info.transform_w],
                        "filters_total": nf_total,
                        "filters_per_gpu": nf if streamed else -(-nf_total // world),
-                       "kernels": ("uploaded from pinned host memory inside every step (SURVEY 8(d)): %d uploads in the %d timed steps, "
-                                   "double-buffered on an upload stream" % (kernel_uploads_timed, args.steps)) if upload_kernels
+                       "kernels": ("uploaded from pinned host memory inside every step (SURVEY 8(d)): %d uploads in the %d timed steps, %s"
+                                   % (kernel_uploads_timed, args.steps,
+                                      "read over PCIe by the kernels' column pass itself (<= 2 MiB: no copy)" if engine.zero_copy
+                                      else "double-buffered on an upload stream")) if upload_kernels
                                   else "resident in HBM",
                        "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps, "settle_s": args.settle_s,
                        "tune_placement": {"candidates": plan.get_option("tuned_candidates"), "kept": plan.get_option("tuned_best")} if tune_k > 1 else None,
@@ -899,7 +901,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     plan.destroy()
-    if rank == 0 and world == 1 and not use_dist and not args.no_extras and result is not None:
+    if rank == 0 and world == 1 and not use_dist and not args.no_extras and result is not None and args.config is None and not streamed and graph is None:
         # untimed for the headline: the MEX-faithful surface (host in / host out) and the F > 1 case, from THIS binary
         del engine, conv, out
         torch.cuda.empty_cache()

@@ -37,6 +37,8 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //   6144 = 16 x 24 x 16, 384 threads (images between 4224 and 6144): 384 / 256 / 384; its F = 1 kernels need <= 128 VGPRs
 //          (4 waves per SIMD), where two 6-wave workgroups do share a CU
 //   5120 = 16 x 20 x 16, 320 threads (round 4): every stage exactly one butterfly per thread: 320 / 256 / 320
+//   4608 = 8 x 24 x 24 (round 4: images of 4300 - 4500):         576 / 192 / 192
+//   2304 = 8 x 24 x 12 (round 4):                                 288 / 96 / 192
 //   3520 = 10 x 16 x 22 (round 4):                                352 / 220 / 160
 //   3072 = 8 x 24 x 16 (images around 2500 - 3000):               384 / 128 / 192
 //   2560 = 8 x 20 x 16 (round 4):                                 320 / 128 / 160
@@ -59,6 +61,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(5120, 16, 20, 16, 320, 1, 4)  \
     X(5120, 16, 20, 16, 320, 1, 20)
 #define FC_FAST_ROW_CONFIGS_G1(X)   \
+    X(4608, 8, 24, 24, 192, 1, 3)   \
+    X(4608, 8, 24, 24, 192, 1, 6)   \
+    X(4608, 8, 24, 24, 192, 1, 24)  \
     X(4224, 8, 24, 22, 192, 1, 3)   \
     X(4224, 8, 24, 22, 192, 1, 6)   \
     X(4224, 8, 24, 22, 192, 1, 24)  \
@@ -72,6 +77,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(2560, 8, 20, 16, 192, 1, 4)   \
     X(2560, 8, 20, 16, 192, 1, 20)
 #define FC_FAST_ROW_CONFIGS_G2(X)   \
+    X(2304, 8, 24, 12, 192, 1, 3)   \
+    X(2304, 8, 24, 12, 192, 1, 6)   \
+    X(2304, 8, 24, 12, 192, 1, 24)  \
     X(2112, 8, 12, 22, 192, 2, 3)   \
     X(2112, 8, 12, 22, 192, 2, 12)  \
     X(1760, 10, 8, 22, 192, 2, 3)   \
@@ -222,16 +230,19 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   M =  544 (FFT_H 1088, cfg2's own window): 2 x 17 x 16, 16 columns, 544 threads
 //   M = 2560 / 1760 / 1280 / 880 / 672 (transforms 5120 / 3520 / 2560 / 1760 / 1344): 8 x 20 x 16 (4 columns),
 //       8 x 10 x 22 (8), 8 x 10 x 16 (8), 5 x 8 x 22 (16), 6 x 8 x 14 (16)
+//   M = 2304 / 1152 (transforms 4608 / 2304): 8 x 12 x 24 (8 columns, 768 threads), 8 x 12 x 12 (8, 768)
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
     X(3072, 8, 24, 16, 4, 768)    \
     X(2560, 8, 20, 16, 4, 640)    \
+    X(2304, 8, 12, 24, 8, 768)    \
     X(2112, 8, 12, 22, 8, 768)    \
     X(2080, 8, 10, 26, 8, 640)    \
     X(1760, 8, 10, 22, 8, 640)
 #define FC_FAST_COL_CONFIGS_G1(X) \
     X(1536, 8, 12, 16, 8, 768)    \
     X(1280, 8, 10, 16, 8, 640)    \
+    X(1152, 8, 12, 12, 8, 768)    \
     X(1056, 6, 8, 22, 16, 768)    \
     X(880, 5, 8, 22, 16, 640)     \
     X(768, 6, 8, 16, 16, 768)     \

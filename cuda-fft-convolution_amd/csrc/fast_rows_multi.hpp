@@ -1,16 +1,15 @@
 // fast_rows_multi.hpp -- spectral-row kernel, several maps per workgroup.
 //
-// fast_rows_body (fast_rows.hpp) gives every (row group, kernel) pair a workgroup of its own:
-// each one pays the launch, the stage-2 twiddle fill, the exposed latency of its kernel-row load
-// and a fresh fetch of the image-spectrum row, and it retires only after its stores have
+// A workgroup per (row group, kernel) pair pays the launch, the stage-2 twiddle fill, the exposed latency of its
+// kernel-row load and a fresh fetch of the image-spectrum row, and it retires only after its stores have
 // drained.  Here a workgroup keeps its image-spectrum row IN REGISTERS and walks G consecutive
-// kernels with it:
+// kernels with it (G = 1: the one-map launch of small problems):
 //   * the image-spectrum row is fetched once per G maps instead of once per map (the largest
 //     read of this kernel: 8*C bytes per map -> 8*C/G);
 //   * the next kernel's row (kw complex values: one or two registers per thread) is prefetched
 //     right after stage 1 has consumed the current one, so its latency hides behind four phases;
 //   * the stores of map m drain while map m + 1 is transformed.
-// The phases are those of fast_rows_body, unchanged; P5 ends with a barrier because the next
+// P5 ends with a barrier because the next
 // map's P1 overwrites the LDS row.
 // MULTIF (F > 1, the reference's sumAlongFeatures case): the walk runs over (map, feature) pairs.  The
 // image-spectrum row of feature f cannot stay in registers (F rows), so it is fetched at the start of

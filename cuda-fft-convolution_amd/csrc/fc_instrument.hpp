@@ -7,7 +7,7 @@
 #pragma once
 
 #if !defined(FC_INSTRUMENT)
-#if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_ROWS1_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
+#if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_NT_SLOADS) ||              \
     defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
@@ -37,9 +37,6 @@
 // ---- spectral-row kernels (fast_rows.hpp, fast_rows_multi.hpp)
 #ifndef FC_NT_SLOADS
 #define FC_NT_SLOADS 0           // 1: streaming loads for the image-spectrum rows
-#endif
-#ifndef FC_ROWS1_DBG
-#define FC_ROWS1_DBG 0           // one-map kernel, wrong results: 1 no stores, 2 no image-spectrum loads, 4 no final phase
 #endif
 #ifndef FC_ROWS_NO_FOLD
 #define FC_ROWS_NO_FOLD 0        // 1: forward stage 1 as a phase of its own for every map

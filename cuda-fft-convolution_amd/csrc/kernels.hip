@@ -143,7 +143,6 @@ hipError_t launch_crop_maps(const float* src, int src_h, size_t src_map_stride, 
 // ---- first group that has the length takes the launch
 #define FC_DECL_GROUP(G)                                                                                                              \
     hipError_t launch_fast_rows_fwd_g##G(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s, bool* matched);                   \
-    hipError_t launch_fast_rows_g##G(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s, bool* matched); \
     hipError_t launch_fast_rows_multi_g##G(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s, bool* matched); \
     hipError_t fast_rows_multi_wgs_per_cu_g##G(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu);
 FC_DECL_GROUP(0) FC_DECL_GROUP(1) FC_DECL_GROUP(2)
@@ -168,14 +167,9 @@ hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipSt
 
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s);
 
-hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s) {
-    if (rows <= 0 || kernels <= 0) return hipSuccess;
-    if (a.F > 1) return launch_fast_rows_multi(L, nz2, a, rows, kernels, 1, s);   // one map per workgroup of the (map, feature) walk
-    bool m = false;
-    hipError_t e = launch_fast_rows_g0(L, nz2, a, rows, kernels, order, s, &m);
-    if (!m) e = launch_fast_rows_g1(L, nz2, a, rows, kernels, order, s, &m);
-    if (!m) e = launch_fast_rows_g2(L, nz2, a, rows, kernels, order, s, &m);
-    return e;
+// one map per workgroup: the multi-map walk with a walk length of 1 (round 4: the separate one-map kernel is gone)
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int /*order*/, hipStream_t s) {
+    return launch_fast_rows_multi(L, nz2, a, rows, kernels, 1, s);
 }
 
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s) {

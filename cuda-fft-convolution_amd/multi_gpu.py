@@ -288,7 +288,11 @@ class HipPlanEngine:
         plan.set_option("defer_prepare", 1 if defer_prepare else 0)
         self.kernels_host = kernels_host if (kernels_host is not None and self.count) else None
         self.uploads = 0
-        if self.kernels_host is not None:
+        # small kernel sets (<= 2 MiB: a few microseconds of PCIe) are not copied at all: the kernels' column pass reads the
+        # pinned host memory itself (pinned memory is mapped into the device's address space), so the step still moves
+        # its kernels over PCIe but pays no copy launch and no cross-stream wait (two waits cost cfg1 / cfg2 ~13 us a step)
+        self.zero_copy = self.kernels_host is not None and self.kernels_host.numel() * self.kernels_host.element_size() <= (2 << 20)
+        if self.kernels_host is not None and not self.zero_copy:
             self.kbuf = [kernels, torch.empty_like(kernels)]
             self.up_stream = torch.cuda.Stream(device)
             self.k_uploaded = [torch.cuda.Event(), torch.cuda.Event()]
@@ -309,6 +313,8 @@ class HipPlanEngine:
         """device pointer of this step's kernels (ordering the plan's stream behind their upload once per step)"""
         if self.kernels_host is None:
             return self.kernels.data_ptr()
+        if self.zero_copy:
+            return self.kernels_host.data_ptr()
         if not self.k_waited:
             self.main_stream.wait_event(self.k_uploaded[self.k_cur])
             self.k_waited = True
@@ -350,7 +356,9 @@ class HipPlanEngine:
         self.plan.mark_spectrum_valid()
         if count:
             self.plan.convolve_packed_device(count, self._kernels_ptr(), self.kh, self.kw, self.out.data_ptr())
-            if self.kernels_host is not None:      # this step's buffer is free once the convolve has read it; the next step's upload starts now
+            if self.zero_copy:
+                self.uploads += 1                  # (read over PCIe by the kernels' column pass of this step)
+            elif self.kernels_host is not None:    # this step's buffer is free once the convolve has read it; the next step's upload starts now
                 self.k_consumed[self.k_cur].record(self.main_stream)
                 self.k_cur ^= 1
                 self.k_waited = False

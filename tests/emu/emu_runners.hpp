@@ -49,7 +49,7 @@ struct EmuFastRows {
                      // the prefetch slot and the LDS reuse are exercised, the indexing is not
     template <class Cfg, int NZ2>
     void go() {
-        if (group > 1 || a.F > 1) {      // (F > 1: always the walk over (map, feature) pairs, as the product's launchers)
+        {   // (always the walk over maps / (map, feature) pairs, as the product's launchers: a walk of one map where group <= 1)
             const int group = this->group > 1 ? this->group : 1;
             FastRowsArgs b = a;
             b.a_kernel_stride = 0;
@@ -69,13 +69,6 @@ struct EmuFastRows {
                     else if constexpr (!ALWAYS_LINEAR) fast_rows_multi_body<Cfg, NZ2, false>(ctx, lds, b, grp, 0, group, rows);
                 }
             }
-            return;
-        }
-        for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
-            // poison the LDS image so that reads of never-written cells show up
-            for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
-            HostPhaseCtx<RowState<Cfg, false>> ctx(Cfg::NT);
-            fast_rows_body<Cfg, NZ2, false>(ctx, lds, a, grp, 0, rows);
         }
     }
 };

@@ -240,6 +240,14 @@ def test_bench_two_ranks_on_one_gpu_cfg4_full_size():
     assert j["n_gpus"] == 2 and j["check_ok"]
     assert j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
     assert j["config"]["filters_total"] == 128 and j["config"]["filters_per_gpu"] == 64
+    # round 4: the N > 1 line proves who took part and where its time went
+    assert len(j["ranks"]) == 2 and all(r["name"] and r["host"] for r in j["ranks"])
+    assert j["distinct_devices"] == 1                      # the rehearsal: both ranks on the one GPU (--share-gpu allows it)
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["filters"] == 64 and r["ms_per_step"] > 0 for r in pr)
+    assert all(r["broadcasts"] >= 3 and r["broadcast_ms_mean"] > 0 for r in pr)      # one broadcast per timed step, timed on every rank
+    assert max(r["ms_per_step"] for r in pr) <= j["ms_per_step"] * 1.05 + 0.5
+    assert "uploaded from pinned host memory inside every step" in j["config"]["kernels"]
     assert "gloo" in j["config"]["backend"]
 
 
@@ -261,6 +269,10 @@ def test_bench_streamed_two_ranks_on_one_gpu_cfg5_full_size():
                 "--no-cpu-baseline"], timeout=1200)
     assert j["n_gpus"] == 2 and j["check_ok"] and j["scaling"] == "weak"
     assert j["check_max_rel_err"] < 1e-4 and j["check_checksum_max_rel_err"] < 1e-5
+    # per rank: its images, the rate of its H2D copies (an event pair around every image's copy), where its pinned images live
+    pr = j["per_rank"]
+    assert [r["images"] for r in pr] == [3, 3] and all(r["h2d_gbps"] and r["h2d_gbps"] > 1.0 for r in pr)
+    assert all("policy" in r["pinned_images_numa"] for r in pr) and "pinned_images_numa" in j["config"]
 
 
 def _gpu_count():

@@ -34,7 +34,9 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 (20, 1700, 2, 5, 50, 1), (1700, 40, 1, 50, 9, 2),       # 1760
                 (16, 2500, 1, 3, 60, 1), (2500, 28, 1, 50, 5, 1),       # 2560
                 (12, 3400, 1, 3, 100, 1), (3400, 28, 1, 100, 5, 1),     # 3520
-                (10, 5000, 1, 3, 110, 1), (5000, 30, 1, 110, 3, 1)]     # 5120
+                (10, 5000, 1, 3, 110, 1), (5000, 30, 1, 110, 3, 1),     # 5120
+                (14, 2200, 1, 3, 70, 1), (2200, 28, 1, 70, 5, 1),       # 2304
+                (10, 4400, 1, 3, 127, 1), (4400, 30, 1, 127, 3, 1)]     # 4608
 # (path_mode, rows_group): path mode 0 generic kernels, 1 specialised kernels + row-major
 # intermediate, 2 (default) specialised kernels + tiled pair-adjacent intermediate; rows_group -1 auto
 VARIANTS = [(0, -1), (1, -1), (2, -1), (2, 0), (2, 3)]
@@ -349,7 +351,8 @@ def test_gpu_native_window_pairs_vs_generic(fftconv, lh, lw):
 @pytest.mark.parametrize("lh,lw", [(288, 288), (576, 768), (768, 576), (1152, 1536), (1536, 1152), (2112, 3072), (3072, 2112),
                                    (4224, 576), (768, 4224), (6144, 288), (288, 6144), (8448, 768), (1536, 8448), (2112, 2112),
                                    # round 4's lengths
-                                   (1344, 1760), (1760, 1344), (2560, 3520), (3520, 2560), (5120, 1344), (1344, 5120), (5120, 5120)])
+                                   (1344, 1760), (1760, 1344), (2560, 3520), (3520, 2560), (5120, 1344), (1344, 5120), (5120, 5120),
+                                   (2304, 4608), (4608, 2304)])
 def test_gpu_every_fast_length_pair_vs_generic(fftconv, lh, lw):
     """both kernels specialised, every transform length at least once along h and along w, 17
     kernels (multi-map walk + remainder), odd data sizes: specialised path against the generic

@@ -9,7 +9,7 @@ import util
 
 pytestmark = pytest.mark.gpu
 
-FAST_LENGTHS = [288, 576, 768, 1152, 1344, 1536, 1760, 2112, 2560, 3072, 3520, 4224, 5120, 6144, 8448]
+FAST_LENGTHS = [288, 576, 768, 1152, 1344, 1536, 1760, 2112, 2304, 2560, 3072, 3520, 4224, 4608, 5120, 6144, 8448]
 
 
 def _cases():

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event times of one device-resident step for arbitrary sizes: profile_shape.py H W K [filters] [F]"""
+import os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, util
+fc = util.load_package()
+H, W, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+F = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+opts = {"exact_window": 1} if os.environ.get("EXACT") else None
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(1)
+img = torch.from_numpy(rng.random((F, W, H), dtype=np.float32)).to(dev)
+ker = torch.from_numpy(rng.random((n, F, K, K), dtype=np.float32)).to(dev)
+with fc.Plan(H, W, F, K, K, options=opts) as p:
+    i = p.info
+    out = torch.empty((n, i.fft_w, i.fft_h), dtype=torch.float32, device=dev)
+    def step():
+        p.set_image_device(img.data_ptr()); p.convolve_packed_device(n, ker.data_ptr(), K, K, out.data_ptr())
+    for _ in range(30): step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20): step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    p.set_option("profile", 1); p.profile(reset=True)
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    pr = p.profile(reset=True)
+    print("%dx%d K=%d F=%d n=%d window %dx%d transform %dx%d spec %d: %.1f us/step  %.1f Gpx/s | " % (H, W, K, F, n, i.fft_h, i.fft_w, i.transform_h, i.transform_w,
+          p.get_option("specialised_kernels"), dt * 1e6, n * i.fft_h * i.fft_w / dt / 1e9) +
+          "  ".join("%s %.1f us x%d" % (k, v["ms"] / max(1, v["launches"]) * 1e3, v["launches"] // 5) for k, v in pr.items()))
