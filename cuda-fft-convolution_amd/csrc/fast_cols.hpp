@@ -75,9 +75,6 @@ struct FastColsArgs {
     // full rounds only; the `tail_tiles` tiles from `tail_first` on are cut into 1 << slice_shift column slices each and
     // dealt one slice per workgroup.  All three are 0 otherwise.
     int tail_first, tail_tiles, slice_shift;
-    // 1 (4-column tiles only): the tiled intermediate is PAIR-INTERLEAVED (FastRowsArgs::y_interleave): the two rows of a bin pair
-    // for the 4 columns of a tile are one contiguous 64-byte piece ([row of the pair][4 columns]) instead of two 32-byte ones
-    int y_interleave;
 };
 
 template <class C>
@@ -164,18 +161,10 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 bool mine = e < State::NPU;
                 if constexpr (SLICED) mine = mine && 2 * (e % T2) >= c_lo && 2 * (e % T2) < c_hi;
                 if (mine) {
-                    if (T == 4 && g.y_interleave) {      // pair block of 32 complex values: [column group][row of the pair][4 columns]
-                        const c32* pr = Yt - (w0 & (tw - 1)) + ((size_t)(e / T2) << 5) + (((w0 & (tw - 1)) >> 2) << 3) + 2 * (e % T2);
-                        if constexpr (!(FC_COLS_DBG & 4)) {
-                            FC_STREAM_LOAD16(st.pa[r], pr);
-                            FC_STREAM_LOAD16(st.pb[r], pr + 4);
-                        }
-                    } else {
                     const c32* pr = Yt + ((size_t)(2 * (e / T2)) << g.y_tile_shift) + 2 * (e % T2);
                     if constexpr (!(FC_COLS_DBG & 4)) {
                         FC_STREAM_LOAD16(st.pa[r], pr);
                         FC_STREAM_LOAD16(st.pb[r], pr + tw);
-                    }
                     }
                 }
             });

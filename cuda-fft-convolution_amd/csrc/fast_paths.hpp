@@ -34,11 +34,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //          one row per 384-thread workgroup only ONE workgroup was ever resident per CU -- at more than 128 VGPRs the
 //          hardware does not admit a second 6-wave workgroup, profiles/r03a_fused_roles_sq_counters.txt: 5.7 waves per CU;
 //          a 12-wave workgroup is resident whole)
-//   6144 = 16 x 24 x 16, 2 rows per workgroup of 768 threads: 384 / 256 / 384 per row (until round 4: one row per 384-thread
-//          workgroup, two workgroups per CU at <= 128 VGPRs)
-//   5120 = 16 x 20 x 16, 2 rows per workgroup of 640 threads (round 4): every stage exactly one butterfly per thread
-//   The three long configurations are PAIRED (RowCfg::PAIRED): the two rows of a workgroup are the rows of one bin pair (k, M - k),
-//   written side by side into the pair-interleaved intermediate so that the output kernel's 4-column tiles gather 64-byte pieces
+//   6144 = 16 x 24 x 16, 384 threads (images between 4224 and 6144): 384 / 256 / 384; its F = 1 kernels need <= 128 VGPRs
+//          (4 waves per SIMD), where two 6-wave workgroups do share a CU
+//   5120 = 16 x 20 x 16, 320 threads (round 4): every stage exactly one butterfly per thread: 320 / 256 / 320
 //   4608 = 8 x 24 x 24 (round 4: images of 4300 - 4500):         576 / 192 / 192
 //   2304 = 8 x 24 x 12 (round 4):                                 288 / 96 / 192
 //   3520 = 10 x 16 x 22 (round 4):                                352 / 220 / 160
@@ -57,11 +55,11 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(8448, 16, 24, 22, 768, 2, 3)  \
     X(8448, 16, 24, 22, 768, 2, 6)  \
     X(8448, 16, 24, 22, 768, 2, 24) \
-    X(6144, 16, 24, 16, 768, 2, 3)  \
-    X(6144, 16, 24, 16, 768, 2, 6)  \
-    X(6144, 16, 24, 16, 768, 2, 24) \
-    X(5120, 16, 20, 16, 640, 2, 4)  \
-    X(5120, 16, 20, 16, 640, 2, 20)
+    X(6144, 16, 24, 16, 384, 1, 3)  \
+    X(6144, 16, 24, 16, 384, 1, 6)  \
+    X(6144, 16, 24, 16, 384, 1, 24) \
+    X(5120, 16, 20, 16, 320, 1, 4)  \
+    X(5120, 16, 20, 16, 320, 1, 20)
 #define FC_FAST_ROW_CONFIGS_G1(X)   \
     X(4608, 8, 24, 24, 192, 1, 3)   \
     X(4608, 8, 24, 24, 192, 1, 6)   \
@@ -116,7 +114,6 @@ struct FastRowsInfo {
     int L = 0, R1 = 0, R2 = 0, R3 = 0, NT = 0, RPW = 1;
     int max_kw = 0;      // largest kernel width the fast kernel accepts
     size_t lds_bytes = 0;
-    bool paired = false; // RowCfg::PAIRED: a workgroup takes the two rows of a bin pair (row_map)
 };
 
 // Is there a fast row kernel for transform length L able to take kernels up to max_kw wide?
@@ -128,7 +125,6 @@ inline FastRowsInfo fast_rows_lookup(int L, int max_kw) {
         if (max_kw <= Cfg::m1) {                                                          \
             r.ok = true; r.L = LL; r.R1 = A; r.R2 = B; r.R3 = C; r.NT = NTT; r.RPW = RP;  \
             r.max_kw = Cfg::m1; r.lds_bytes = (size_t)Cfg::LDS_ELEMS * sizeof(c32);       \
-            r.paired = Cfg::PAIRED;                                                       \
         }                                                                                 \
     }
     FC_FAST_ROW_CONFIGS(FC_X)

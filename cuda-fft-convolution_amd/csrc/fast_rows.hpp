@@ -40,11 +40,6 @@ struct RowCfg {
     static constexpr int RND2 = (RPW * NB2 + NT - 1) / NT;
     static constexpr int T2N = (R2 - 1) * R3;  // stage-2 twiddle entries
     static constexpr int LDS_ELEMS = RPW * L + T2N;  // c32
-    // Long rows (two per workgroup of >= 640 threads: 5120, 6144, 8448 points): the two rows of a workgroup are the rows of
-    // one BIN PAIR (k, M - k) of the h-transform, taken from FastRowsArgs::row_map, so that the workgroup can write both rows of
-    // the pair side by side (pair-interleaved intermediate, see y_interleave) and the 4-column tiles of the output kernel
-    // gather 64-byte pieces instead of 32-byte ones
-    static constexpr bool PAIRED = RPW == 2 && NT >= 640;
     static_assert(R1 * R2 * R3 == L, "radices must multiply to L");
     static_assert(RPW * NB3 <= NT, "one stage-3 butterfly per thread");
     static_assert(R3 % 2 == 0, "register-order layout pairs stage-3 elements");
@@ -81,18 +76,7 @@ struct FastRowsArgs {
     int y_tile_elems;        // (M+1) * TL
     int y_tile_shift;        // log2(TL)
     unsigned long long* timeline;  // FC_ROWS_TIMELINE builds only: per-phase wall-clock stamps of one workgroup (else unused)
-    // PAIRED configurations: row_map[group * 2 + rr] = spectrum row of the workgroup's rr-th row (>= rows: none).
-    const int* row_map;
-    // 1: pair-interleaved tiles -- inside a 16-column tile the two rows of a bin pair (tile rows 2p, 2p + 1) are stored as
-    //    [column group of 4][row of the pair][4 columns] (32 complex values per pair), i.e. element (tile row r, column c) at
-    //    (r >> 1) * 32 + ((c >> 2) * 2 + (r & 1)) * 4 + (c & 3).  Consumed by the 4-column tiles of the output kernel.
-    int y_interleave;
 };
-
-// column c of a 16-column tile -> offset inside a pair block of the pair-interleaved layout (row part excluded)
-FC_HD int interleave_col(int c) { return ((c >> 2) << 3) + (c & 3); }
-// tile row r -> offset of its pair block + its half
-FC_HD int interleave_row(int r) { return ((r >> 1) << 5) + ((r & 1) << 2); }
 
 // p[c] = w^c, c in [1, R)
 template <int R>

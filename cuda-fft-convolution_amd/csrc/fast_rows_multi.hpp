@@ -29,10 +29,6 @@ struct RowMultiState {
     c32 x[C::RND1];      // kernel row of the current / next map
     c32 w1[C::RND1];     // stage-1 base twiddle w_L^j of this thread's butterflies (same for every map)
     int yoff[C::RND1];   // tiled intermediate: element offset of this thread's rows (same for every map)
-    // PAIRED configurations (rows from FastRowsArgs::row_map): spectrum row of this thread's stage-1 butterflies (>= rows: none)
-    // and of its stage-3 butterfly, looked up once in the prologue
-    int xrow[C::PAIRED ? C::RND1 : 1];
-    int srow;
 };
 
 // columns per tile of the tiled intermediate (pipeline.hpp: Geometry::y_tile_w)
@@ -55,12 +51,6 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
     const int row0 = group * RPW;
     const bool tiled = g.y_row_of != nullptr;
     constexpr bool FOLD = !(FC_ROWS_NO_FOLD);
-    // spectrum row of this workgroup's rr-th row (PAIRED configurations: the rows of one bin pair, from a table)
-    auto row_of = [&](int rr) -> int {
-        if constexpr (C::PAIRED) return g.row_map[row0 + rr];
-        else return row0 + rr;
-    };
-    const bool ilv = C::PAIRED && tiled && g.y_interleave;   // pair-interleaved tiles (fast_rows.hpp)
 
     auto load_x = [&](int t, State& st, int kernel, int f) {
         const c32* abase = g.A + (size_t)kernel * g.a_kernel_stride + (MULTIF ? (size_t)f * g.a_feat_stride : 0);
@@ -69,9 +59,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             int u = t + NT * r;
             if constexpr (MULTIF) FC_OPAQUE(u);   // F > 1: index arithmetic recomputed per step, not hoisted out of the walk and spilled
             const int rr = u / C::NB1, j = u - rr * C::NB1;
-            int row;
-            if constexpr (C::PAIRED) row = st.xrow[r];
-            else row = row0 + rr;
+            const int row = row0 + rr;
             st.x[r] = (rr < RPW && row < rows && j < kw) ? abase[(size_t)row * g.a_pitch + j] : mk(0.f, 0.f);
         });
     };
@@ -79,16 +67,6 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
     // once per workgroup: stage-2 twiddles into LDS, first kernel row, image-spectrum row
     ctx.phase_nosync([&](int t, State& st) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
-        if constexpr (C::PAIRED) {
-            static_for<0, C::RND1>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
-                const int u = t + NT * r;
-                const int rr = u / C::NB1;
-                st.xrow[r] = rr < RPW ? row_of(rr) : rows;
-            });
-            const int rr3 = t / C::NB3;
-            st.srow = rr3 < RPW ? row_of(rr3) : rows;
-        }
         load_x(t, st, kernel0, 0);
         // loaded once: inside the walk a global load in P5 would have to be waited for together
         // with the stores issued just before it (one in-order memory counter)
@@ -96,20 +74,15 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             constexpr int r = decltype(r_)::value;
             const int u = t + NT * r;
             const int rr = u / C::NB1, j = u - rr * C::NB1;
-            int row;
-            if constexpr (C::PAIRED) row = st.xrow[r];
-            else row = row0 + rr;
+            const int row = row0 + rr;
             const bool live = rr < RPW && row < rows;
             st.w1[r] = live ? g.tw1[j] : mk(1.f, 0.f);
-            st.yoff[r] = live ? (tiled ? (ilv ? interleave_row(g.y_row_of[row]) : (g.y_row_of[row] << g.y_tile_shift)) : row * g.y_pitch) : 0;
+            st.yoff[r] = live ? (tiled ? (g.y_row_of[row] << g.y_tile_shift) : row * g.y_pitch) : 0;
         });
         if constexpr (!MULTIF) {
             const int rr = t / C::NB3, q = t - rr * C::NB3;
-            int srow_i;
-            if constexpr (C::PAIRED) srow_i = st.srow;
-            else srow_i = row0 + rr;
-            if (rr < RPW && srow_i < rows) {
-                const c32* srow = g.S + (size_t)srow_i * g.s_pitch;
+            if (rr < RPW && row0 + rr < rows) {
+                const c32* srow = g.S + (size_t)(row0 + rr) * g.s_pitch;
                 static_for<0, R3 / 2>([&](auto h_) {
                     constexpr int h = decltype(h_)::value;
                     c32x2 v = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
@@ -202,8 +175,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 constexpr int S_EARLY_CFG = (RPW > 1 || R3 > 22) ? 0 : FC_MULTIF_S_EARLY;
                 constexpr int S_EARLY = (S_EARLY_CFG < R3 / 2) ? S_EARLY_CFG : R3 / 2;
                 if constexpr (MULTIF && (0) < (S_EARLY)) {
-                    if ((C::PAIRED ? st.srow : row0 + rr) < rows) {
-                        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(C::PAIRED ? st.srow : row0 + rr) * g.s_pitch;
+                    if (row0 + rr < rows) {
+                        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(row0 + rr) * g.s_pitch;
                         static_for<(0), (S_EARLY)>([&](auto h_) {
                             constexpr int h = decltype(h_)::value;
                             c32x2 w = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
@@ -240,8 +213,8 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 }
                 Dft<R3, -1>::run(v);
                 if constexpr (MULTIF && (S_EARLY) < (R3 / 2)) {
-                    if ((C::PAIRED ? st.srow : row0 + rr) < rows) {
-                        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(C::PAIRED ? st.srow : row0 + rr) * g.s_pitch;
+                    if (row0 + rr < rows) {
+                        const c32* srow = g.S + (size_t)f * g.s_feat_stride + (size_t)(row0 + rr) * g.s_pitch;
                         static_for<(S_EARLY), (R3 / 2)>([&](auto h_) {
                             constexpr int h = decltype(h_)::value;
                             c32x2 w = *reinterpret_cast<const c32x2*>(srow + (size_t)(h * C::NB3 + q) * 2);
@@ -334,7 +307,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     int u = t + NT * r;
                     FC_OPAQUE(u);
                     const int rr = u / C::NB1, j = u - rr * C::NB1;
-                    if (rr < RPW && (C::PAIRED ? st.xrow[C::PAIRED ? r : 0] : row0 + rr) < rows) {
+                    if (rr < RPW && row0 + rr < rows) {
                         const c32* buf = lds + rr * L;
                         c32 p[R1];
                         c32 v[R1];
@@ -350,8 +323,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         });
                         Dft<R1, +1>::run(v);
                         }
-                        const int jc = j & ((1 << g.y_tile_shift) - 1);
-                        const int jo = tiled ? (j >> g.y_tile_shift) * g.y_tile_elems + (ilv ? interleave_col(jc) : jc) : j;
+                        const int jo = tiled ? (j >> g.y_tile_shift) * g.y_tile_elems + (j & ((1 << g.y_tile_shift) - 1)) : j;
                         const unsigned off0 = (unsigned)(st.yoff[r] + jo) * (unsigned)sizeof(c32);
                         if (g.wout >= L) {   // nothing cropped (uniform)
                             static_for<0, R1>([&](auto a_) {
@@ -381,7 +353,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 int u = t + NT * r;
                 FC_OPAQUE(u);   // twiddle chains and store offsets are recomputed per map, not kept (spilled) across the loop
                 const int rr = u / C::NB1, j = u - rr * C::NB1;
-                const int row = C::PAIRED ? st.xrow[C::PAIRED ? r : 0] : row0 + rr;
+                const int row = row0 + rr;
                 if (rr < RPW && row < rows) {
                     const c32* buf = lds + rr * L;
                     c32 p[R1];
@@ -398,8 +370,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         constexpr int a = decltype(a_)::value;
                         int w = j + a * m1;
                         if (w < g.wout) {
-                            const int wc = w & ((1 << g.y_tile_shift) - 1);
-                            if (tiled) FC_ROWSM_STORE(&yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (ilv ? interleave_col(wc) : wc)], v[a]);
+                            if (tiled) FC_ROWSM_STORE(&yrow[(size_t)(w >> g.y_tile_shift) * g.y_tile_elems + (w & ((1 << g.y_tile_shift) - 1))], v[a]);
                             else FC_ROWSM_STORE(&yrow[w], v[a]);
                         }
                     });

@@ -354,7 +354,7 @@ struct fftconv_plan {
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
     DevBuf<c32> fr_tw1, fr_tw2;
-    DevBuf<int> fr_map, fr_rowmap;
+    DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
     DevBuf<int> fc_rowoff, fc_pair_row_of;
@@ -442,7 +442,7 @@ struct fftconv_plan {
         pool.clear();
         tw_m.release(); tw_w.release(); pairs.release();
         S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); OC.release(); I.release();
-        fr_tw1.release(); fr_tw2.release(); fr_map.release(); fr_rowmap.release();
+        fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_pair_row_of.release();
         nat_row_of.release(); nat_col_of.release(); NS.release();
     }
@@ -1331,11 +1331,6 @@ int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feat
             p->d.fr_tw1 = p->fr_tw1.p;
             p->d.fr_tw2 = p->fr_tw2.p;
             p->d.fr_relayout = p->fr_map.p;
-            if (p->g.rows_paired()) {
-                if ((rc = p->fr_rowmap.ensure(p->t.row_map.size()))) break;
-                if ((rc = cp(p->fr_rowmap.p, p->t.row_map.data(), p->t.row_map.size() * sizeof(int)))) break;
-                p->d.fr_row_map = p->fr_rowmap.p;
-            }
         }
     } while (0);
     if (rc) {

@@ -59,10 +59,6 @@ struct Geometry {
     static constexpr int y_tile_shift = FC_Y_TILE_SHIFT;
     bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
     int tile_rows() const { return y_tiled() ? M + 2 : rows; }
-    // long rows (two per workgroup of >= 640 threads: FastRowsInfo::paired): a workgroup takes the two rows of one bin pair; with
-    // the 4-column output tiles the pair is stored interleaved (fast_rows.hpp: y_interleave) so that a tile gathers 64-byte pieces
-    bool rows_paired() const { return fast_rows.ok && fast_rows.paired; }
-    bool y_interleave() const { return y_tiled() && rows_paired() && fast_cols.T == 4; }
     int rows_wg_order = 0;     // workgroup order of the one-map row kernel (kernels_rows.hip: k_fast_rows); 2 for F > 1
     int rows_group = -1;       // PlanTuning::rows_group
     bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && fast_rows.ok; }
@@ -113,8 +109,6 @@ struct Tables {
     FastColsTables fcl; // only if Geometry::fast_cols.ok
     // natural h-frequency y -> spectrum row, natural w-frequency x -> element of a stored image-spectrum row
     std::vector<int> nat_row_of, nat_col_of;
-    // paired row configurations: row_map[2 g + rr] = spectrum row of row rr of workgroup g (>= rows: none)
-    std::vector<int> row_map;
 };
 
 // returns false if the sizes are invalid / unsupported
@@ -168,20 +162,6 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, producer, g.y_pitch);
     t.nat_row_of.assign(g.rows, g.M);                       // bin M (Nyquist) lives in the extra row M
     for (int k = 0; k < g.M; k++) t.nat_row_of[k] = producer.pos[k];
-    if (g.rows_paired()) {
-        // groups of two rows: the rows of bin pair p (tile rows 2p, 2p + 1 of the pair-adjacent intermediate) where the output
-        // kernel is specialised, else simply rows (2g, 2g + 1)
-        const int groups = (g.rows + 1) / 2;
-        t.row_map.assign((size_t)2 * groups, g.rows);
-        if (g.fast_cols.ok) {
-            for (int i = 0; i < g.rows; i++) {
-                const int r = t.fcl.pair_row_of[i];          // 2p or 2p + 1
-                if (r < 2 * groups) t.row_map[r] = i;
-            }
-        } else {
-            for (int i = 0; i < g.rows; i++) t.row_map[i] = i;
-        }
-    }
     t.nat_col_of.assign(g.Lw, 0);
     if (g.fast_rows.ok) {                                   // stored element x holds transform position relayout[x]
         std::vector<int> inv(g.Lw, 0);
@@ -206,7 +186,6 @@ struct DeviceTables {
     const PairEntry* fc_pairs = nullptr;
     const int* fc_rowoff = nullptr;
     const int* fc_pair_row_of = nullptr;
-    const int* fr_row_map = nullptr;
     unsigned long long* timeline = nullptr;   // FC_ROWS_TIMELINE / FC_COLS_TIMELINE builds only (plan option "timeline_ptr")
 };
 
@@ -274,8 +253,6 @@ inline FastRowsArgs fast_rows_args(const Geometry& g, const DeviceTables& d, con
     a.y_row_of = g.y_tiled() ? d.fc_pair_row_of : nullptr;
     a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift;
     a.timeline = d.timeline;
-    a.row_map = g.rows_paired() ? d.fr_row_map : nullptr;
-    a.y_interleave = g.y_interleave() ? 1 : 0;
     return a;
 }
 
@@ -289,7 +266,6 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
     a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift;
     a.timeline = d.timeline;
-    a.y_interleave = g.y_interleave() ? 1 : 0;
     return a;
 }
 

@@ -102,7 +102,6 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             if (kw[k] > g.fast_rows.max_kw) return -4;
             d.fr_tw1 = t.fr.tw1.data();
             d.fr_tw2 = t.fr.tw2.data();
-            d.fr_row_map = t.row_map.empty() ? nullptr : t.row_map.data();
             FastRowsArgs fa = fast_rows_args(g, d, A.data(), kw[k], S, Y.data());
             EmuFastRows run{fa, lds.data(), g.rows, (g.rows_multi_ok() && g.rows_group > 1) ? g.rows_group : 0};
             if (!run_fast_rows(g.Lw, fast_rows_nz2(g, kw[k]), run)) return -5;

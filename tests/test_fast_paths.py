@@ -181,24 +181,6 @@ def test_emulated_native_window_kernels(emu, oracle, tuned, shape, variant):
         emu.emu_set_exact_window(0)
 
 
-@pytest.mark.skipif(not os.environ.get("FFTCONV_SLOW_TESTS"), reason="5 minutes of host emulation: set FFTCONV_SLOW_TESTS=1 (the GPU tier covers the "
-                                                                       "same path against the generic kernels: 5120 x 5120, 6000 x 6000, 8192 x 8192)")
-def test_emulated_paired_rows_and_interleaved_tiles(emu, oracle, tuned):
-    """The long row configurations (5120 / 6144 / 8448 points) give a workgroup the two rows of one bin pair and, where the
-    output kernel runs 4-column tiles (M >= 2560), store the pair interleaved so that a tile gathers 64-byte pieces: a
-    5120 x 5120 transform through the emulator (the GPU tier covers 6144 and 8448 against the generic kernels)."""
-    tuned((2, -1))
-    shape = (4900, 4900, 1, 63, 63, 1)
-    H, W, F, kh, kw, n = shape
-    lh, lw = ctypes.c_int(0), ctypes.c_int(0)
-    assert emu.emu_plan_lengths(H, W, F, kh, kw, ctypes.byref(lh), ctypes.byref(lw)) == 0 and (lh.value, lw.value) == (5120, 5120)
-    assert emu.emu_uses_fast_rows(H, W, F, kh, kw) == 3
-    data, ks = make_inputs(shape, 71)
-    rc, got = emu_conv(emu, data, kh, kw, ks)
-    assert rc == 0
-    assert util.rel_err(got[0], oracle.conv_fft(data, kh, kw, ks)[0]) < 1e-5
-
-
 def test_fast_row_kernel_rejects_too_wide_kernels(emu):
     # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224); plans for
     # wider MAX_KERNEL_W fall back to the generic kernel at plan time
