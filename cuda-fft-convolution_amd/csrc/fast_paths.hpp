@@ -39,6 +39,8 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //   5120 = 16 x 20 x 16, 320 threads (round 4): every stage exactly one butterfly per thread: 320 / 256 / 320
 //   4608 = 8 x 24 x 24 (round 4: images of 4300 - 4500):         576 / 192 / 192
 //   2304 = 8 x 24 x 12 (round 4):                                 288 / 96 / 192
+//   7680 = 16 x 20 x 24 and 7040 = 10 x 32 x 22 (20 x 16 x 22 spilled 4 registers), 2 rows per workgroup of 640 threads; 5632 = 16 x 16 x 22, 256 threads;
+//   3840 = 8 x 20 x 24; 2816 = 8 x 16 x 22; 1920 = 8 x 12 x 20, 2 rows (round 4, second batch: what tools/size_sweep.py showed missing)
 //   3520 = 10 x 16 x 22 (round 4):                                352 / 220 / 160
 //   3072 = 8 x 24 x 16 (images around 2500 - 3000):               384 / 128 / 192
 //   2560 = 8 x 20 x 16 (round 4):                                 320 / 128 / 160
@@ -55,9 +57,16 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(8448, 16, 24, 22, 768, 2, 3)  \
     X(8448, 16, 24, 22, 768, 2, 6)  \
     X(8448, 16, 24, 22, 768, 2, 24) \
+    X(7680, 16, 20, 24, 640, 2, 3)  \
+    X(7680, 16, 20, 24, 640, 2, 20) \
+    X(7040, 10, 32, 22, 640, 2, 3)  \
+    X(7040, 10, 32, 22, 640, 2, 6)  \
+    X(7040, 10, 32, 22, 640, 2, 32) \
     X(6144, 16, 24, 16, 384, 1, 3)  \
     X(6144, 16, 24, 16, 384, 1, 6)  \
     X(6144, 16, 24, 16, 384, 1, 24) \
+    X(5632, 16, 16, 22, 256, 1, 3)  \
+    X(5632, 16, 16, 22, 256, 1, 16) \
     X(5120, 16, 20, 16, 320, 1, 4)  \
     X(5120, 16, 20, 16, 320, 1, 20)
 #define FC_FAST_ROW_CONFIGS_G1(X)   \
@@ -69,11 +78,15 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(4224, 8, 24, 22, 192, 1, 24)  \
     X(4160, 10, 16, 26, 192, 1, 3)  \
     X(4160, 10, 16, 26, 192, 1, 16) \
+    X(3840, 8, 20, 24, 192, 1, 3)   \
+    X(3840, 8, 20, 24, 192, 1, 20)  \
     X(3520, 10, 16, 22, 192, 1, 3)  \
     X(3520, 10, 16, 22, 192, 1, 16) \
     X(3072, 8, 24, 16, 192, 1, 3)   \
     X(3072, 8, 24, 16, 192, 1, 6)   \
     X(3072, 8, 24, 16, 192, 1, 24)  \
+    X(2816, 8, 16, 22, 192, 1, 3)   \
+    X(2816, 8, 16, 22, 192, 1, 16)  \
     X(2560, 8, 20, 16, 192, 1, 4)   \
     X(2560, 8, 20, 16, 192, 1, 20)
 #define FC_FAST_ROW_CONFIGS_G2(X)   \
@@ -82,6 +95,8 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(2304, 8, 24, 12, 192, 1, 24)  \
     X(2112, 8, 12, 22, 192, 2, 3)   \
     X(2112, 8, 12, 22, 192, 2, 12)  \
+    X(1920, 8, 12, 20, 192, 2, 3)   \
+    X(1920, 8, 12, 20, 192, 2, 12)  \
     X(1760, 10, 8, 22, 192, 2, 3)   \
     X(1760, 10, 8, 22, 192, 2, 8)   \
     X(1536, 8, 12, 16, 192, 2, 3)   \
@@ -142,6 +157,7 @@ inline double fast_rows_factor(int L, int max_kw) {
     if (!fast_rows_length(L, max_kw)) return 0.0;
     if (L == 1088) return FC_FACTOR_1088;
     if (L == 4160) return FC_FACTOR_4160;
+    if (L >= 5120) return 0.60;      // the long-row configurations run at ~270 Gpx/s-equivalent against ~360 up to 4608 points
     return 0.45;
 }
 
@@ -231,19 +247,27 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //   M = 2560 / 1760 / 1280 / 880 / 672 (transforms 5120 / 3520 / 2560 / 1760 / 1344): 8 x 20 x 16 (4 columns),
 //       8 x 10 x 22 (8), 8 x 10 x 16 (8), 5 x 8 x 22 (16), 6 x 8 x 14 (16)
 //   M = 2304 / 1152 (transforms 4608 / 2304): 8 x 12 x 24 (8 columns, 768 threads), 8 x 12 x 12 (8, 768)
+//   M = 3840 / 3520 / 2816 / 1920 / 1408 / 960 (transforms 7680 / 7040 / 5632 / 3840 / 2816 / 1920): 8 x 20 x 24 (4 columns),
+//       8 x 20 x 22 (4), 8 x 22 x 16 (4, 704 threads), 8 x 10 x 24 (8), 8 x 11 x 16 (8, 704), 6 x 8 x 20 (16)
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
+    X(3840, 8, 20, 24, 4, 640)    \
+    X(3520, 8, 20, 22, 4, 640)    \
     X(3072, 8, 24, 16, 4, 768)    \
+    X(2816, 8, 22, 16, 4, 704)    \
     X(2560, 8, 20, 16, 4, 640)    \
     X(2304, 8, 12, 24, 8, 768)    \
     X(2112, 8, 12, 22, 8, 768)    \
     X(2080, 8, 10, 26, 8, 640)    \
+    X(1920, 8, 10, 24, 8, 640)    \
     X(1760, 8, 10, 22, 8, 640)
 #define FC_FAST_COL_CONFIGS_G1(X) \
     X(1536, 8, 12, 16, 8, 768)    \
+    X(1408, 8, 11, 16, 8, 704)    \
     X(1280, 8, 10, 16, 8, 640)    \
     X(1152, 8, 12, 12, 8, 768)    \
     X(1056, 6, 8, 22, 16, 768)    \
+    X(960, 6, 8, 20, 16, 768)     \
     X(880, 5, 8, 22, 16, 640)     \
     X(768, 6, 8, 16, 16, 768)     \
     X(672, 6, 8, 14, 16, 768)     \
@@ -284,6 +308,7 @@ inline double fast_cols_factor(int M, int) {
     if (!fast_cols_lookup(M).ok) return 0.0;
     if (M == 544) return FC_FACTOR_1088;
     if (M == 2080) return FC_FACTOR_4160;
+    if (M >= 2560) return 0.60;      // 4-column tiles
     return 0.45;
 }
 

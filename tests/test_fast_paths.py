@@ -36,7 +36,13 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 (12, 3400, 1, 3, 100, 1), (3400, 28, 1, 100, 5, 1),     # 3520
                 (10, 5000, 1, 3, 110, 1), (5000, 30, 1, 110, 3, 1),     # 5120
                 (14, 2200, 1, 3, 70, 1), (2200, 28, 1, 70, 5, 1),       # 2304
-                (10, 4400, 1, 3, 127, 1), (4400, 30, 1, 127, 3, 1)]     # 4608
+                (10, 4400, 1, 3, 127, 1), (4400, 30, 1, 127, 3, 1),     # 4608
+                (20, 1850, 1, 3, 63, 1), (1850, 28, 1, 63, 5, 1),       # 1920
+                (14, 2700, 1, 3, 90, 1), (2700, 28, 1, 90, 5, 1),       # 2816
+                (12, 3750, 1, 3, 60, 1), (3750, 30, 1, 60, 3, 1),       # 3840
+                (10, 5500, 1, 3, 100, 1), (5500, 30, 1, 100, 3, 1),     # 5632
+                (10, 6900, 1, 3, 127, 1), (6900, 30, 1, 127, 3, 1),     # 7040
+                (10, 7500, 1, 3, 127, 1), (7500, 30, 1, 127, 3, 1)]     # 7680
 # (path_mode, rows_group): path mode 0 generic kernels, 1 specialised kernels + row-major
 # intermediate, 2 (default) specialised kernels + tiled pair-adjacent intermediate; rows_group -1 auto
 VARIANTS = [(0, -1), (1, -1), (2, -1), (2, 0), (2, 3)]
@@ -182,19 +188,22 @@ def test_emulated_native_window_kernels(emu, oracle, tuned, shape, variant):
 
 
 def test_fast_row_kernel_rejects_too_wide_kernels(emu):
-    # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224); plans for
+    # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224, 704 for L = 7040, the widest); plans for
     # wider MAX_KERNEL_W fall back to the generic kernel at plan time
-    assert emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) == 0
+    assert emu.emu_uses_fast_rows(12, 3600, 1, 3, 800) == 0
 
 
 def test_planner_discounts_only_lengths_whose_row_kernel_takes_max_kw(emu):
     """the length preference knows MAX_KERNEL_W: 4224 is preferred for 127-wide kernels, but a plan
-    for 600-wide kernels (wider than the fast kernel's 528) is not steered to a length it cannot use fast"""
+    for 800-wide kernels (wider than any fast kernel takes) is not steered to a length it cannot use fast"""
     lh, lw = ctypes.c_int(0), ctypes.c_int(0)
     assert emu.emu_plan_lengths(12, 4096, 1, 3, 127, ctypes.byref(lh), ctypes.byref(lw)) == 0
     assert lw.value == 4224
+    assert emu.emu_plan_lengths(12, 3600, 1, 3, 800, ctypes.byref(lh), ctypes.byref(lw)) == 0
+    assert lw.value >= 4399 and emu.emu_uses_fast_rows(12, 3600, 1, 3, 800) == 0
+    # 600-wide kernels: wider than the 4224-point kernel takes (528), so the plan moves to a length whose kernel does (7040: 704)
     assert emu.emu_plan_lengths(12, 3600, 1, 3, 600, ctypes.byref(lh), ctypes.byref(lw)) == 0
-    assert lw.value >= 4199 and emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) == 0
+    assert emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) in (0, 1) and (lw.value == 7040) == (emu.emu_uses_fast_rows(12, 3600, 1, 3, 600) == 1)
 
 
 # ------------------------------------------------------------------------------------ GPU tier
@@ -352,7 +361,8 @@ def test_gpu_native_window_pairs_vs_generic(fftconv, lh, lw):
                                    (4224, 576), (768, 4224), (6144, 288), (288, 6144), (8448, 768), (1536, 8448), (2112, 2112),
                                    # round 4's lengths
                                    (1344, 1760), (1760, 1344), (2560, 3520), (3520, 2560), (5120, 1344), (1344, 5120), (5120, 5120),
-                                   (2304, 4608), (4608, 2304)])
+                                   (2304, 4608), (4608, 2304), (1920, 2816), (2816, 1920), (3840, 5632), (5632, 3840), (7040, 1920), (1920, 7680),
+                                   (7680, 7040)])
 def test_gpu_every_fast_length_pair_vs_generic(fftconv, lh, lw):
     """both kernels specialised, every transform length at least once along h and along w, 17
     kernels (multi-map walk + remainder), odd data sizes: specialised path against the generic

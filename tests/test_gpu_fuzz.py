@@ -9,7 +9,8 @@ import util
 
 pytestmark = pytest.mark.gpu
 
-FAST_LENGTHS = [288, 576, 768, 1152, 1344, 1536, 1760, 2112, 2304, 2560, 3072, 3520, 4224, 4608, 5120, 6144, 8448]
+FAST_LENGTHS = [288, 576, 768, 1152, 1344, 1536, 1760, 1920, 2112, 2304, 2560, 2816, 3072, 3520, 3840, 4224, 4608, 5120, 5632, 6144,
+                7040, 7680, 8448]
 
 
 def _cases():
