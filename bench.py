@@ -334,12 +334,8 @@ def rank_identity(torch, dev):
     import socket
     props = torch.cuda.get_device_properties(dev)
     bus = None
-    try:   # hipDeviceGetPCIBusId through the HIP runtime torch has loaded
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev.index or 0)) == 0:
-            bus = buf.value.decode()
+    try:   # (from torch's own device properties: no second HIP runtime is loaded into the process for this)
+        bus = "%04x:%02x:%02x.0" % (int(props.pci_domain_id), int(props.pci_bus_id), int(props.pci_device_id))
     except Exception:
         bus = None
     uuid = getattr(props, "uuid", None)
@@ -845,7 +841,7 @@ def main():
                        "filters_per_gpu": nf if streamed else -(-nf_total // world),
                        "kernels": ("uploaded from pinned host memory inside every step (SURVEY 8(d)): %d uploads in the %d timed steps, %s"
                                    % (kernel_uploads_timed, args.steps,
-                                      "read over PCIe by the kernels' column pass itself (<= 2 MiB: no copy)" if engine.zero_copy
+                                      "read over PCIe by the kernels' column pass itself (<= 512 KiB: no copy)" if engine.zero_copy
                                       else "double-buffered on an upload stream")) if upload_kernels
                                   else "resident in HBM",
                        "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps, "settle_s": args.settle_s,

@@ -93,6 +93,30 @@ struct ColPairState {
     c32x2 pb[RNDU];      // row of bin M-k (or Nyquist / padding)
 };
 
+// Bin pair a gather unit takes (tiled intermediate).  With 4-column tiles a 16-lane LDS access group lands 8 pairs x 2 column
+// pairs; consecutive pairs k, k + 1 sit m1 = M / R1 positions apart in the LDS image, which is a multiple of all 32 banks for
+// most of these configurations (M = 4224: 528 complex = 1056 dwords) -- an 8-way conflict on every landing store.  So inside
+// every full block of 64 pairs the order is transposed 8 x 8: the pairs of one access group are then 8 apart, i.e. R3 cells
+// apart in the image (44 dwords at R3 = 22: eight distinct bank pairs).  Where R3 cells are a multiple of the 32 banks
+// themselves (R3 = 16) the pairs of a group are taken NB3 = R1 * R2 apart instead -- they differ in the LAST digit of their
+// position and land in 8 consecutive cells -- inside superblocks of 8 * NB3 pairs, the 8 x 8 form for what is left.
+// Output kernel per launch, same box (profiles/r04g_cols4_landing_order.txt): M = 4224 141.8 -> 126.1 us per map; M = 3072
+// 2468 -> 2202 us per 32 maps, M = 2560 1668 -> 1568; for R3 = 22 / 24 the NB3 form is 1-4 % slower than the 8 x 8 one.
+template <class C>
+FC_HD int pair_of_unit(int u) {
+    if constexpr (C::T == 4 && FC_COLS_PAIR_TRANSPOSE) {
+        constexpr int NP = C::M / 2 + 1, SB = 8 * C::NB3;
+        constexpr int FULL = ((2 * C::R3) % 32 == 0) ? (NP / SB) * SB : 0;
+        if (u < FULL) {
+            const int sb = u / SB, i = u - sb * SB;
+            return sb * SB + (i & 7) * C::NB3 + (i >> 3);
+        }
+        return ((u | 63) < NP) ? ((u & ~63) | ((u & 7) << 3) | ((u >> 3) & 7)) : u;
+    } else {
+        return u;
+    }
+}
+
 // TILED: layout of the intermediate -- false: row-major [i][y_pitch] (the producer is a generic
 // kernel), gathered through `rowoff` and merged by a table-driven pair pass over LDS; true: tiled
 // with the rows of bins (k, M-k) adjacent: one thread gathers both rows of a pair for two columns
@@ -161,7 +185,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 bool mine = e < State::NPU;
                 if constexpr (SLICED) mine = mine && 2 * (e % T2) >= c_lo && 2 * (e % T2) < c_hi;
                 if (mine) {
-                    const c32* pr = Yt + ((size_t)(2 * (e / T2)) << g.y_tile_shift) + 2 * (e % T2);
+                    const c32* pr = Yt + ((size_t)(2 * pair_of_unit<C>(e / T2)) << g.y_tile_shift) + 2 * (e % T2);
                     if constexpr (!(FC_COLS_DBG & 4)) {
                         FC_STREAM_LOAD16(st.pa[r], pr);
                         FC_STREAM_LOAD16(st.pb[r], pr + tw);
@@ -186,7 +210,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 bool mine = e < State::NPU;
                 if constexpr (SLICED) mine = mine && 2 * (e % T2) >= c_lo && 2 * (e % T2) < c_hi;
                 if (mine) {
-                    const int k = e / T2, t2 = e % T2;
+                    const int k = pair_of_unit<C>(e / T2), t2 = e % T2;
                     const unsigned pp = ppos[k];
                     const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
                     c32* z0 = lds + (2 * t2) * LP;

@@ -62,13 +62,14 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(7040, 10, 32, 22, 640, 2, 3)  \
     X(7040, 10, 32, 22, 640, 2, 6)  \
     X(7040, 10, 32, 22, 640, 2, 32) \
-    X(6144, 16, 24, 16, 384, 1, 3)  \
-    X(6144, 16, 24, 16, 384, 1, 6)  \
-    X(6144, 16, 24, 16, 384, 1, 24) \
+    X(6144, 8, 32, 24, 256, 1, 3)   \
+    X(6144, 8, 32, 24, 256, 1, 6)   \
+    X(6144, 8, 32, 24, 256, 1, 32)  \
     X(5632, 16, 16, 22, 256, 1, 3)  \
     X(5632, 16, 16, 22, 256, 1, 16) \
-    X(5120, 16, 20, 16, 320, 1, 4)  \
-    X(5120, 16, 20, 16, 320, 1, 20)
+    X(5120, 8, 32, 20, 256, 1, 4)   \
+    X(5120, 8, 32, 20, 256, 1, 7)   \
+    X(5120, 8, 32, 20, 256, 1, 32)
 #define FC_FAST_ROW_CONFIGS_G1(X)   \
     X(4608, 8, 24, 24, 192, 1, 3)   \
     X(4608, 8, 24, 24, 192, 1, 6)   \

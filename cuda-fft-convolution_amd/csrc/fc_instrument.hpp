@@ -8,7 +8,7 @@
 
 #if !defined(FC_INSTRUMENT)
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
-    defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_NT_SLOADS) ||              \
+    defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
     defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
@@ -30,6 +30,9 @@
 #ifndef FC_COLS_SPLIT_GATHER
 #define FC_COLS_SPLIT_GATHER 2   // next tile's gather issued in: 0 one go at the start of the tile, 1 halves (start, after stage 3),
 #endif                           // 2 thirds (start, after stage 3, between the two rounds of stage 2): 28.3 / 27.4 / 27.2 us per map
+#ifndef FC_COLS_PAIR_TRANSPOSE
+#define FC_COLS_PAIR_TRANSPOSE 1 // 4-column tiles: pairs of one LDS access group 8 apart instead of consecutive (fast_cols.hpp: pair_of_unit)
+#endif
 #ifndef FC_COLS_NO_PREWAIT
 #define FC_COLS_NO_PREWAIT 0     // 1: without the vmcnt(0) ahead of the store burst
 #endif

@@ -288,10 +288,11 @@ class HipPlanEngine:
         plan.set_option("defer_prepare", 1 if defer_prepare else 0)
         self.kernels_host = kernels_host if (kernels_host is not None and self.count) else None
         self.uploads = 0
-        # small kernel sets (<= 2 MiB: a few microseconds of PCIe) are not copied at all: the kernels' column pass reads the
+        # small kernel sets (<= 512 KiB: a few microseconds of PCIe) are not copied at all: the kernels' column pass reads the
         # pinned host memory itself (pinned memory is mapped into the device's address space), so the step still moves
-        # its kernels over PCIe but pays no copy launch and no cross-stream wait (two waits cost cfg1 / cfg2 ~13 us a step)
-        self.zero_copy = self.kernels_host is not None and self.kernels_host.numel() * self.kernels_host.element_size() <= (2 << 20)
+        # its kernels over PCIe but pays no copy launch and no cross-stream wait (two waits cost cfg1 / cfg2 ~13 us a step);
+        # larger sets take the upload stream, which hides the copy behind the previous step
+        self.zero_copy = self.kernels_host is not None and self.kernels_host.numel() * self.kernels_host.element_size() <= (512 << 10)
         if self.kernels_host is not None and not self.zero_copy:
             self.kbuf = [kernels, torch.empty_like(kernels)]
             self.up_stream = torch.cuda.Stream(device)

@@ -9,8 +9,9 @@ OBJ=/tmp/fc_variant_$NAME
 mkdir -p $OBJ $ROOT/cuda-fft-convolution_amd/ab
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function -DFC_INSTRUMENT $*"
 pids=""
-for f in kernels kernels_rows kernels_rows_multi kernels_cols kernels_cols_fwd; do
-  /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o & pids="$pids $!"
+for src in $SRC/kernels*.hip; do      # kernels.hip + one translation unit per kernel family and configuration group
+  f=$(basename $src .hip)
+  /opt/rocm/bin/hipcc $FLAGS -I$SRC -c $src -o $OBJ/$f.o & pids="$pids $!"
 done
 /opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_api.cpp -o $OBJ/fftconv_api.o & pids="$pids $!"
 /opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_multi.cpp -o $OBJ/fftconv_multi.o & pids="$pids $!"
