@@ -31,8 +31,8 @@
 #define FC_COLS_SPLIT_GATHER 2   // next tile's gather issued in: 0 one go at the start of the tile, 1 halves (start, after stage 3),
 #endif                           // 2 thirds (start, after stage 3, between the two rounds of stage 2): 28.3 / 27.4 / 27.2 us per map
 #ifndef FC_COLS_PAIR_TRANSPOSE
-#define FC_COLS_PAIR_TRANSPOSE 1 // 4-column tiles: pairs of one LDS access group 8 apart instead of consecutive (fast_cols.hpp: pair_of_unit)
-#endif
+#define FC_COLS_PAIR_TRANSPOSE 2 // landing order of the bin pairs (fast_cols.hpp: pair_of_unit): 0 consecutive, 1 permuted for 4-column tiles,
+#endif                           // 2 also for the 8-column configurations whose consecutive pairs share a bank
 #ifndef FC_COLS_NO_PREWAIT
 #define FC_COLS_NO_PREWAIT 0     // 1: without the vmcnt(0) ahead of the store burst
 #endif
