@@ -419,7 +419,7 @@ def main():
     ap.add_argument("--kernel-chunk-mb", type=int, default=0, help="budget of the kernels' column-spectrum chunk (0 = the library's default; A/B)")
     ap.add_argument("--tune-placement", type=int, default=-1,
                     help="candidate allocations of the intermediate the plan times against the map buffer (plan option "
-                         "tune_placement; -1 = 3 where a launch covers >= 5e8 padded pixels, else off; 0 = off)")
+                         "tune_placement; -1 = 5 where a launch covers >= 5e8 padded pixels, else off; 0 = off)")
     ap.add_argument("--rows-group", type=int, default=0, help="maps per workgroup of the spectral-row kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
@@ -543,7 +543,8 @@ def main():
     if args.kernel_chunk_mb:
         plan.set_option("kernel_chunk_mb", args.kernel_chunk_mb)
     # placement tuning (untimed set-up, like a plan's measuring): only where launches are long enough to tell 4 % apart
-    tune_k = args.tune_placement if args.tune_placement >= 0 else (3 if min(args.batch_maps or 64, max(nf, 1)) * P >= 5e8 else 0)
+    # (5 candidates since round 4: with 3 one box in five still ended in the slow state, every candidate in a slow region)
+    tune_k = args.tune_placement if args.tune_placement >= 0 else (5 if min(args.batch_maps or 64, max(nf, 1)) * P >= 5e8 else 0)
     if tune_k > 1:
         plan.set_option("tune_placement", tune_k)
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
