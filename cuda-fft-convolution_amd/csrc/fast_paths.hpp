@@ -83,13 +83,12 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(3840, 8, 20, 24, 192, 1, 20)  \
     X(3520, 10, 16, 22, 192, 1, 3)  \
     X(3520, 10, 16, 22, 192, 1, 16) \
-    X(3072, 8, 24, 16, 192, 1, 3)   \
-    X(3072, 8, 24, 16, 192, 1, 6)   \
-    X(3072, 8, 24, 16, 192, 1, 24)  \
+    X(3072, 8, 32, 12, 256, 1, 6)   \
+    X(3072, 8, 32, 12, 256, 1, 32)  \
     X(2816, 8, 16, 22, 192, 1, 3)   \
     X(2816, 8, 16, 22, 192, 1, 16)  \
-    X(2560, 8, 20, 16, 192, 1, 4)   \
-    X(2560, 8, 20, 16, 192, 1, 20)
+    X(2560, 8, 32, 10, 256, 1, 7)   \
+    X(2560, 8, 32, 10, 256, 1, 32)
 #define FC_FAST_ROW_CONFIGS_G2(X)   \
     X(2304, 8, 24, 12, 192, 1, 3)   \
     X(2304, 8, 24, 12, 192, 1, 6)   \
@@ -100,8 +99,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(1920, 8, 12, 20, 192, 2, 12)  \
     X(1760, 10, 8, 22, 192, 2, 3)   \
     X(1760, 10, 8, 22, 192, 2, 8)   \
-    X(1536, 8, 12, 16, 192, 2, 3)   \
-    X(1536, 8, 12, 16, 192, 2, 12)  \
+    X(1536, 8, 16, 12, 256, 2, 3)   \
+    X(1536, 8, 16, 12, 256, 2, 6)   \
+    X(1536, 8, 16, 12, 256, 2, 16)  \
     X(1344, 6, 16, 14, 192, 2, 3)   \
     X(1344, 6, 16, 14, 192, 2, 16)  \
     X(1152, 8, 12, 12, 192, 2, 3)   \
@@ -109,8 +109,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(1152, 8, 12, 12, 192, 2, 12)  \
     X(1088, 17, 4, 16, 192, 2, 2)   \
     X(1088, 17, 4, 16, 192, 2, 4)   \
-    X(768, 4, 12, 16, 192, 4, 3)    \
-    X(768, 4, 12, 16, 192, 4, 12)   \
+    X(768, 4, 16, 12, 256, 4, 3)    \
+    X(768, 4, 16, 12, 256, 4, 6)    \
+    X(768, 4, 16, 12, 256, 4, 16)   \
     X(576, 4, 12, 12, 192, 4, 3)    \
     X(576, 4, 12, 12, 192, 4, 12)   \
     X(288, 4, 6, 12, 192, 8, 3)     \
