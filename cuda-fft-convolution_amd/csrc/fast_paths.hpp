@@ -40,14 +40,18 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //   4608 = 8 x 24 x 24 (round 4: images of 4300 - 4500):         576 / 192 / 192
 //   2304 = 8 x 24 x 12 (round 4):                                 288 / 96 / 192
 //   7680 = 16 x 20 x 24 and 7040 = 10 x 32 x 22 (20 x 16 x 22 spilled 4 registers), 2 rows per workgroup of 640 threads; 5632 = 16 x 16 x 22, 256 threads;
-//   3840 = 8 x 20 x 24; 2816 = 8 x 16 x 22; 1920 = 8 x 12 x 20, 2 rows (round 4, second batch: what tools/size_sweep.py showed missing)
+//   3840 = 8 x 24 x 20; 2816 = 8 x 16 x 22; 2304 = 8 x 16 x 18, 2 rows of 256 threads; 1920 = 8 x 12 x 20, 2 rows (round 4, second batch: what tools/size_sweep.py showed missing)
 //   3520 = 10 x 16 x 22 (round 4):                                352 / 220 / 160
-//   3072 = 8 x 24 x 16 (images around 2500 - 3000):               384 / 128 / 192
-//   2560 = 8 x 20 x 16 (round 4):                                 320 / 128 / 160
+//   3072 = 8 x 32 x 12, 256 threads (round 4; was 8 x 24 x 16):   384 / 96 / 256
+//   2560 = 8 x 32 x 10, 256 threads (round 4):                    320 / 80 / 256
 //   1760 = 10 x 8 x 22, 2 rows (round 4):                         352 / 440 / 160
-//   1536 = 8 x 12 x 16, 2 rows (1280-wide images):                384 / 256 / 192
+//   1536 = 8 x 16 x 12, 2 rows, 256 threads (round 4; was 8 x 12 x 16): 384 / 192 / 256
 //   1344 = 6 x 16 x 14, 2 rows (round 4):                         448 / 168 / 192
-//    768 = 4 x 12 x 16, 4 rows (640 / 720-sized images):          768 / 256 / 192
+//   Stage-3 runs of R3 values are read and written 16 bytes at a time, R3 * 8 bytes apart per lane: 128 bytes at R3 = 16 -- the
+//   same banks for every lane of an access group, an 8-way conflict (4-way at R3 = 24, 2-way at 12 / 20, none at 10, 14, 18, 22,
+//   26).  Round 4 moved the R3 = 16 configurations to R3 = 12 / 10 with stage 2 in one round (rows -11 ... -25 %, same-box A/B in
+//   profiles/r04h_row_configs_ab.txt); 4608 as 8 x 32 x 18 and 1152 as 8 x 8 x 18 x4 measured SLOWER than the listed forms.
+//    768 = 4 x 16 x 12, 4 rows, 256 threads (round 4; was 4 x 12 x 16): 768 / 192 / 256
 //    576 = 4 x 12 x 12, 4 rows (512-sized images):                576 / 192 / 192
 //    288 = 4 x  6 x 12, 8 rows (cfg1):                            576 / 384 / 192
 // Round 4's lengths close the gaps of the ladder: a transform is at most ~1.2 x the padded size per dimension instead of
@@ -79,8 +83,8 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(4224, 8, 24, 22, 192, 1, 24)  \
     X(4160, 10, 16, 26, 192, 1, 3)  \
     X(4160, 10, 16, 26, 192, 1, 16) \
-    X(3840, 8, 20, 24, 192, 1, 3)   \
-    X(3840, 8, 20, 24, 192, 1, 20)  \
+    X(3840, 8, 24, 20, 192, 1, 4)   \
+    X(3840, 8, 24, 20, 192, 1, 24)  \
     X(3520, 10, 16, 22, 192, 1, 3)  \
     X(3520, 10, 16, 22, 192, 1, 16) \
     X(3072, 8, 32, 12, 256, 1, 6)   \
@@ -90,9 +94,8 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(2560, 8, 32, 10, 256, 1, 7)   \
     X(2560, 8, 32, 10, 256, 1, 32)
 #define FC_FAST_ROW_CONFIGS_G2(X)   \
-    X(2304, 8, 24, 12, 192, 1, 3)   \
-    X(2304, 8, 24, 12, 192, 1, 6)   \
-    X(2304, 8, 24, 12, 192, 1, 24)  \
+    X(2304, 8, 16, 18, 256, 2, 4)   \
+    X(2304, 8, 16, 18, 256, 2, 16)  \
     X(2112, 8, 12, 22, 192, 2, 3)   \
     X(2112, 8, 12, 22, 192, 2, 12)  \
     X(1920, 8, 12, 20, 192, 2, 3)   \
@@ -253,29 +256,29 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //       8 x 20 x 22 (4), 8 x 22 x 16 (4, 704 threads), 8 x 10 x 24 (8), 8 x 11 x 16 (8, 704), 6 x 8 x 20 (16)
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
-    X(3840, 8, 20, 24, 4, 640)    \
+    X(3840, 8, 24, 20, 4, 768)    \
     X(3520, 8, 20, 22, 4, 640)    \
-    X(3072, 8, 24, 16, 4, 768)    \
-    X(2816, 8, 22, 16, 4, 704)    \
-    X(2560, 8, 20, 16, 4, 640)    \
-    X(2304, 8, 12, 24, 8, 768)    \
+    X(3072, 8, 32, 12, 4, 1024)    \
+    X(2816, 8, 16, 22, 4, 512)    \
+    X(2560, 8, 32, 10, 4, 1024)    \
+    X(2304, 8, 16, 18, 8, 1024)    \
     X(2112, 8, 12, 22, 8, 768)    \
     X(2080, 8, 10, 26, 8, 640)    \
-    X(1920, 8, 10, 24, 8, 640)    \
+    X(1920, 8, 12, 20, 8, 768)    \
     X(1760, 8, 10, 22, 8, 640)
 #define FC_FAST_COL_CONFIGS_G1(X) \
-    X(1536, 8, 12, 16, 8, 768)    \
-    X(1408, 8, 11, 16, 8, 704)    \
-    X(1280, 8, 10, 16, 8, 640)    \
+    X(1536, 8, 16, 12, 8, 1024)    \
+    X(1408, 8, 8, 22, 8, 512)    \
+    X(1280, 8, 16, 10, 8, 1024)    \
     X(1152, 8, 12, 12, 8, 768)    \
     X(1056, 6, 8, 22, 16, 768)    \
     X(960, 6, 8, 20, 16, 768)     \
     X(880, 5, 8, 22, 16, 640)     \
-    X(768, 6, 8, 16, 16, 768)     \
+    X(768, 8, 8, 12, 16, 1024)     \
     X(672, 6, 8, 14, 16, 768)     \
     X(576, 6, 8, 12, 16, 768)     \
     X(544, 2, 17, 16, 16, 544)    \
-    X(384, 4, 6, 16, 16, 384)     \
+    X(384, 4, 8, 12, 16, 512)     \
     X(288, 4, 6, 12, 16, 384)     \
     X(144, 4, 6, 6, 16, 384)
 #define FC_FAST_COL_CONFIGS(X) FC_FAST_COL_CONFIGS_G0(X) FC_FAST_COL_CONFIGS_G1(X)
