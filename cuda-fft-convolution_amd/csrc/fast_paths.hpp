@@ -20,43 +20,23 @@ namespace fc {
 // convenient length (1152 / 4224) and crops; exact_window plans use the window's own kernels regardless
 constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 
-// X(L, R1, R2, R3, NT, RPW, NZ2): see fast_rows.hpp.  NT = 192 threads (3 waves) for rows up to 4224 points;
-// RPW rows per workgroup chosen so that RPW * R1 * R2 (the stage-3 butterflies) fill the lanes.
-//   4224 = 8 x 24 x 22 (cfg3; cfg4's 4160 window can run on it and crop): butterflies 528 / 176 / 192
-//   4160 = 10 x 16 x 26 (round 4: cfg4's window itself -- the reference's own cuFFT size, src/cudaConvolutionFFT.cu:103-110 --
-//          needed by exact_window plans, i.e. the spectrum exchange in the reference's order): 416 / 260 / 160
-//   2112 = 8 x 12 x 22, 2 rows (cfg5):                            528 / 352 / 192
-//   1152 = 8 x 12 x 12, 2 rows:                                   288 / 192 / 192   (round 3: was 6 x 8 x 24 with 4 rows per workgroup --
-//          160 registers, 3 waves per SIMD, 145 row groups; the lighter radix-12 stage 3 needs about 100 and twice as many,
-//          half as long workgroup steps fill the chip better: cfg2 196 -> 209 Gpx/s, 256 filters 321 -> 335)
-//   1088 = 17 x 4 x 16, 2 rows (round 4: cfg2's window itself):   128 / 544 / 136; kernels up to 64 wide
-//   8448 = 16 x 24 x 22, 2 rows per workgroup of 768 threads (8192-sized images): 528 / 352 / 384 per row.  (Round 3: as
-//          one row per 384-thread workgroup only ONE workgroup was ever resident per CU -- at more than 128 VGPRs the
-//          hardware does not admit a second 6-wave workgroup, profiles/r03a_fused_roles_sq_counters.txt: 5.7 waves per CU;
-//          a 12-wave workgroup is resident whole)
-//   6144 = 16 x 24 x 16, 384 threads (images between 4224 and 6144): 384 / 256 / 384; its F = 1 kernels need <= 128 VGPRs
-//          (4 waves per SIMD), where two 6-wave workgroups do share a CU
-//   5120 = 16 x 20 x 16, 320 threads (round 4): every stage exactly one butterfly per thread: 320 / 256 / 320
-//   4608 = 8 x 24 x 24 (round 4: images of 4300 - 4500):         576 / 192 / 192
-//   2304 = 8 x 24 x 12 (round 4):                                 288 / 96 / 192
-//   7680 = 16 x 20 x 24 and 7040 = 10 x 32 x 22 (20 x 16 x 22 spilled 4 registers), 2 rows per workgroup of 640 threads; 5632 = 16 x 16 x 22, 256 threads;
-//   3840 = 8 x 24 x 20; 2816 = 8 x 16 x 22; 2304 = 8 x 16 x 18, 2 rows of 256 threads; 1920 = 8 x 12 x 20, 2 rows (round 4, second batch: what tools/size_sweep.py showed missing)
-//   3520 = 10 x 16 x 22 (round 4):                                352 / 220 / 160
-//   3072 = 8 x 32 x 12, 256 threads (round 4; was 8 x 24 x 16):   384 / 96 / 256
-//   2560 = 8 x 32 x 10, 256 threads (round 4):                    320 / 80 / 256
-//   1760 = 10 x 8 x 22, 2 rows (round 4):                         352 / 440 / 160
-//   1536 = 8 x 16 x 12, 2 rows, 256 threads (round 4; was 8 x 12 x 16): 384 / 192 / 256
-//   1344 = 6 x 16 x 14, 2 rows (round 4):                         448 / 168 / 192
-//   Stage-3 runs of R3 values are read and written 16 bytes at a time, R3 * 8 bytes apart per lane: 128 bytes at R3 = 16 -- the
-//   same banks for every lane of an access group, an 8-way conflict (4-way at R3 = 24, 2-way at 12 / 20, none at 10, 14, 18, 22,
-//   26).  Round 4 moved the R3 = 16 configurations to R3 = 12 / 10 with stage 2 in one round (rows -11 ... -25 %, same-box A/B in
-//   profiles/r04h_row_configs_ab.txt); 4608 as 8 x 32 x 18 and 1152 as 8 x 8 x 18 x4 measured SLOWER than the listed forms.
-//    768 = 4 x 16 x 12, 4 rows, 256 threads (round 4; was 4 x 12 x 16): 768 / 192 / 256
-//    576 = 4 x 12 x 12, 4 rows (512-sized images):                576 / 192 / 192
-//    288 = 4 x  6 x 12, 8 rows (cfg1):                            576 / 384 / 192
-// Round 4's lengths close the gaps of the ladder: a transform is at most ~1.2 x the padded size per dimension instead of
-// 1.45 x (tools/size_sweep.py).  Listed with ascending NZ2 per length (the dispatcher takes the first that covers the
-// kernel).  Three groups, one translation unit each per kernel family (kernels_rows*_g?.hip): build time only.
+// X(L, R1, R2, R3, NT, RPW, NZ2): see fast_rows.hpp.  RPW rows of L = R1 x R2 x R3 points per workgroup of NT threads, chosen so that
+// RPW * R1 * R2 (the stage-3 butterflies, one per thread) fill the lanes and stage 2 takes one round where possible; NZ2 = non-zero
+// stage-2 inputs the variant reads (kernel width <= NZ2 * R3), listed ascending per length (the dispatcher takes the first that
+// covers the kernel).  What shaped the list (HISTORY.md; A/B files under profiles/):
+//   * BASELINE: 4224 = 8.24.22 (cfg3; cfg4's 4160 window runs on it and crops), 2112 = 8.12.22 x2 (cfg5), 1152 = 8.12.12 x2 (cfg2's
+//     1088 window), 288 = 4.6.12 x8 (cfg1).  4160 = 10.16.26 and 1088 = 17.4.16 x2 are those two windows' OWN kernels: 10-19 % slower
+//     than the convenient length + crop (r04b_native_window_ab.txt), used by exact_window plans only (planner factors above).
+//   * Round 4 filled the ladder (r04z_size_sweep.txt): a transform is at most ~1.13 x the padded size per dimension above 1000 pixels.
+//   * Long rows: 160 KB of LDS hold two rows of >= 7040 points (one 640- / 768-thread workgroup per CU); 5120 ... 6144 run one row per
+//     256-thread workgroup, three workgroups per CU (r04g: -11 ... -25 % against the R1 = 16 forms on 320 / 384 threads).  More than
+//     128 VGPRs forbid a second 6-wave workgroup on a CU (round 3), hence no 384-thread configurations.
+//   * Stage 3 reads and writes its run of R3 values 16 bytes at a time, lane q's run R3 * 8 bytes after lane q - 1's: 128 bytes at
+//     R3 = 16 -- every lane of an LDS access group on the same banks (8-way conflict), 4-way at R3 = 24, 2-way at 12 / 20, none at 10,
+//     14, 18, 22, 26.  The R3 = 16 forms went (r04h_row_and_column_configs_ab.txt: rows -11 ... -25 %); 4608 as 8.32.18 and 1152 as
+//     8.8.18 x4 measured SLOWER than the listed 8.24.24 / 8.12.12 x2 -- bank conflicts are one term, not the whole cost.
+//   * Radix orders at 4224 (round 2): 8.24.22 25.0 us per map, 12.16.22 25.6, 11.16.24 27.3, 16.12.22 28.0: small R1, fat stage 3.
+// Three groups, one translation unit each per kernel family (kernels_rows*_g?.hip): build time only.
 #define FC_FAST_ROW_CONFIGS_G0(X)   \
     X(8448, 16, 24, 22, 768, 2, 3)  \
     X(8448, 16, 24, 22, 768, 2, 6)  \
@@ -233,27 +213,16 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 }
 
 // ---------------------------------------------------------------------------------------
-// Output (column) kernel configurations: X(M, R1, R2, R3, T, NT), see fast_cols.hpp.
-// M = 2112 (FFT_H = 4224, cfg3): 8 x 12 x 22, 8 columns per tile, 768 threads:
-//   stage butterflies per tile 2112 / 1408 / 768 -> 2.75 / 1.83 / 1.0 rounds of 768 lanes.
-// ---------------------------------------------------------------------------------------
-//   M = 1056 (FFT_H 2112, cfg5): 6 x 8 x 22, 16 columns per tile (full 128-byte lines), 768 threads
-//   M =  576 (transform 1152): 6 x 8 x 12, 16 columns, 768 threads
-//   M = 4224 (transform 8448, 8192-sized images): 8 x 24 x 22, 4 columns per tile (LDS), 768 threads
-//   M = 3072 (transform 6144): 8 x 24 x 16, 4 columns per tile, 768 threads
-//   M = 1536 / 768 / 384 (transforms 3072 / 1536 / 768): 8 x 12 x 16 (8 columns), 6 x 8 x 16, 4 x 6 x 16
-//   M =  288 (transform 576, 512-sized images): 4 x 6 x 12, 16 columns, 384 threads
-//   M =  144 (FFT_H 288, cfg1): 4 x 6 x 6, 16 columns, 384 threads
-//   (M = 2112 as 4 columns / 384 threads, two workgroups per CU, was measured much slower: 32-byte
-//   gather pieces, 47.8 vs 36.1 us per map)
-//   Round 4 (one stage-3 butterfly per thread fixes NT = R1 * R2 * T; 640 threads = 10 waves where 768 do not divide):
-//   M = 2080 (FFT_H 4160, cfg4's own window): 8 x 10 x 26, 8 columns, 640 threads
-//   M =  544 (FFT_H 1088, cfg2's own window): 2 x 17 x 16, 16 columns, 544 threads
-//   M = 2560 / 1760 / 1280 / 880 / 672 (transforms 5120 / 3520 / 2560 / 1760 / 1344): 8 x 20 x 16 (4 columns),
-//       8 x 10 x 22 (8), 8 x 10 x 16 (8), 5 x 8 x 22 (16), 6 x 8 x 14 (16)
-//   M = 2304 / 1152 (transforms 4608 / 2304): 8 x 12 x 24 (8 columns, 768 threads), 8 x 12 x 12 (8, 768)
-//   M = 3840 / 3520 / 2816 / 1920 / 1408 / 960 (transforms 7680 / 7040 / 5632 / 3840 / 2816 / 1920): 8 x 20 x 24 (4 columns),
-//       8 x 20 x 22 (4), 8 x 22 x 16 (4, 704 threads), 8 x 10 x 24 (8), 8 x 11 x 16 (8, 704), 6 x 8 x 20 (16)
+// Output (column) kernel configurations: X(M, R1, R2, R3, T, NT), see fast_cols.hpp: M = R1 x R2 x R3 complex points (transform
+// length 2M along h), T columns per tile, NT = R1 * R2 * T threads (one stage-3 butterfly per thread).  T = 16 (full 128-byte lines of
+// the tiled intermediate) while 16 columns fit the LDS (M <= 1056), 8 up to M = 2304, 4 above.  The forward column kernel
+// (fast_cols_fwd.hpp) runs the same configurations.
+//   * cfg3: M = 2112 = 8.12.22, 8 columns, 768 threads (4 columns / 384 threads, two workgroups per CU, measured 47.8 against 36.1 us
+//     per map in round 1); cfg5: 1056 = 6.8.22; cfg2: 576 = 6.8.12; cfg1: 144 = 4.6.6.
+//   * Round 4: the R3 = 16 / 24 forms were replaced (stage-3 bank conflicts, see the row list): output kernel -2 ... -15 % for eleven
+//     lengths (r04h_row_and_column_configs_ab.txt); 1024-thread workgroups (16 waves, <= 128 VGPRs) where R3 = 10 / 12 / 18 needs
+//     them.  M = 1152 as 8.8.18 / T = 16, 576 as 4.8.18 and 288 as 6.8.6 measured no better than the listed forms.
+//   * M = 2080 = 8.10.26 and 544 = 2.17.16: the cfg4 / cfg2 windows' own kernels (exact_window plans); 2080 spills 12 registers.
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
     X(3840, 8, 24, 20, 4, 768)    \
