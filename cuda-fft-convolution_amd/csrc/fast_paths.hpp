@@ -41,8 +41,8 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(8448, 16, 24, 22, 768, 2, 3)  \
     X(8448, 16, 24, 22, 768, 2, 6)  \
     X(8448, 16, 24, 22, 768, 2, 24) \
-    X(7680, 16, 20, 24, 640, 2, 3)  \
-    X(7680, 16, 20, 24, 640, 2, 20) \
+    X(7680, 16, 24, 20, 768, 2, 4)  \
+    X(7680, 16, 24, 20, 768, 2, 24) \
     X(7040, 10, 32, 22, 640, 2, 3)  \
     X(7040, 10, 32, 22, 640, 2, 6)  \
     X(7040, 10, 32, 22, 640, 2, 32) \
