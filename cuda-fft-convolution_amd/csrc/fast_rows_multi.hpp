@@ -38,7 +38,7 @@ constexpr int FC_Y_TILE_W = 16, FC_Y_TILE_SHIFT = 4;
 inline bool fast_rows_multi_linear(const FastRowsArgs& g, int L, int m1) {
     const bool tiled = g.y_row_of != nullptr;
     (void)L;
-    return !tiled || (m1 & ((1 << g.y_tile_shift) - 1)) == 0;
+    return !tiled || ((2 * m1) & ((1 << g.y_tile_shift) - 1)) == 0;     // whole tiles, or half tiles (two chains: even / odd outputs)
 }
 
 template <class C, int NZ2, bool LINEAR, bool MULTIF = false, class Ctx>
@@ -299,9 +299,14 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
             // of layout tiles (or the intermediate is row-major) and nothing is cropped, output a
             // sits at base + a * stride: a scalar base, one 32-bit add per store, no 64-bit tile
             // arithmetic (a fifth of this kernel's VALU instructions; a cropped window adds a compare)
+            // Where m1 is an odd number of HALF tiles (2112 = 8.12.22: 264 columns = 16.5 tiles; 288 = 4.6.12: 72) the even and the
+            // odd outputs form two such chains, 2 * m1 columns apart each: two bases instead of one (round 4: cfg5 and cfg1 had
+            // run the general form below until then).
             if constexpr (LINEAR) {
                 char* yb = reinterpret_cast<char*>(ybase);
-                const unsigned stride_b = (unsigned)((tiled ? (m1 >> g.y_tile_shift) * g.y_tile_elems : m1) * (int)sizeof(c32));
+                constexpr bool TWO_CHAINS = (m1 % FC_Y_TILE_W) != 0;
+                constexpr int SA = TWO_CHAINS ? 2 : 1;            // outputs a and a + SA are SA * m1 columns = whole tiles apart
+                const unsigned stride_b = (unsigned)((tiled ? ((SA * m1) >> g.y_tile_shift) * g.y_tile_elems : SA * m1) * (int)sizeof(c32));
                 static_for<0, C::RND1>([&](auto r_) {
                     constexpr int r = decltype(r_)::value;
                     int u = t + NT * r;
@@ -325,15 +330,23 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         }
                         const int jo = tiled ? (j >> g.y_tile_shift) * g.y_tile_elems + (j & ((1 << g.y_tile_shift) - 1)) : j;
                         const unsigned off0 = (unsigned)(st.yoff[r] + jo) * (unsigned)sizeof(c32);
+                        unsigned off1 = off0;                      // base of the odd outputs (TWO_CHAINS)
+                        if constexpr (TWO_CHAINS) {
+                            const int j1 = j + m1;
+                            const int jo1 = tiled ? (j1 >> g.y_tile_shift) * g.y_tile_elems + (j1 & ((1 << g.y_tile_shift) - 1)) : j1;
+                            off1 = (unsigned)(st.yoff[r] + jo1) * (unsigned)sizeof(c32);
+                        }
                         if (g.wout >= L) {   // nothing cropped (uniform)
                             static_for<0, R1>([&](auto a_) {
                                 constexpr int a = decltype(a_)::value;
-                                FC_ROWSM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                                const unsigned base = (TWO_CHAINS && (a & 1)) ? off1 : off0;
+                                FC_ROWSM_STORE(reinterpret_cast<c32*>(yb + (size_t)(base + (unsigned)(a / SA) * stride_b)), v[a]);
                             });
                         } else {             // cropped window (cfg4: 4160 columns of the 4224 transform)
                             static_for<0, R1>([&](auto a_) {
                                 constexpr int a = decltype(a_)::value;
-                                if (j + a * m1 < g.wout) FC_ROWSM_STORE(reinterpret_cast<c32*>(yb + (size_t)(off0 + (unsigned)a * stride_b)), v[a]);
+                                const unsigned base = (TWO_CHAINS && (a & 1)) ? off1 : off0;
+                                if (j + a * m1 < g.wout) FC_ROWSM_STORE(reinterpret_cast<c32*>(yb + (size_t)(base + (unsigned)(a / SA) * stride_b)), v[a]);
                             });
                         }
                         if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read

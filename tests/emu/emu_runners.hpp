@@ -57,7 +57,7 @@ struct EmuFastRows {
             for (int grp = 0; grp < (rows + Cfg::RPW - 1) / Cfg::RPW; grp++) {
                 for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
                 // (as the product's launcher: LINEAR is the only variant of a configuration whose m1 is a whole number of tiles)
-                constexpr bool ALWAYS_LINEAR = Cfg::m1 % FC_Y_TILE_W == 0;
+                constexpr bool ALWAYS_LINEAR = (2 * Cfg::m1) % FC_Y_TILE_W == 0;
                 const bool linear = ALWAYS_LINEAR || fast_rows_multi_linear(b, Cfg::L, Cfg::m1);
                 if (a.F > 1) {   // the walk over (map, feature) pairs
                     HostPhaseCtx<RowMultiState<Cfg, true>> ctx(Cfg::NT);
