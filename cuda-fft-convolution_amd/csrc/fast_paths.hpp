@@ -231,7 +231,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(2816, 8, 16, 22, 4, 512)    \
     X(2560, 8, 32, 10, 4, 1024)    \
     X(2304, 8, 16, 18, 8, 1024)    \
-    X(2112, 8, 12, 22, 8, 768)    \
+    X(2112, 6, 16, 22, 8, 768)    \
     X(2080, 8, 10, 26, 8, 640)    \
     X(1920, 8, 12, 20, 8, 768)    \
     X(1760, 8, 10, 22, 8, 640)
