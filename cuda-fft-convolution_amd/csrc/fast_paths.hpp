@@ -226,7 +226,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
     X(3840, 8, 24, 20, 4, 768)    \
-    X(3520, 8, 20, 22, 4, 640)    \
+    X(3520, 10, 16, 22, 4, 640)    \
     X(3072, 8, 32, 12, 4, 1024)    \
     X(2816, 8, 16, 22, 4, 512)    \
     X(2560, 8, 32, 10, 4, 1024)    \
