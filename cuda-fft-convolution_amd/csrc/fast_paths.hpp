@@ -34,7 +34,10 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //   * Stage 3 reads and writes its run of R3 values 16 bytes at a time, lane q's run R3 * 8 bytes after lane q - 1's: 128 bytes at
 //     R3 = 16 -- every lane of an LDS access group on the same banks (8-way conflict), 4-way at R3 = 24, 2-way at 12 / 20, none at 10,
 //     14, 18, 22, 26.  The R3 = 16 forms went (r04h_row_and_column_configs_ab.txt: rows -11 ... -25 %); 4608 as 8.32.18 and 1152 as
-//     8.8.18 x4 measured SLOWER than the listed 8.24.24 / 8.12.12 x2 -- bank conflicts are one term, not the whole cost.
+//     8.8.18 x4 measured SLOWER than the R3 = 24 / 12 forms -- bank conflicts are one term, not the whole cost.
+//   * A search over every admissible (R1, R2, R3, threads) of each length (tools/config_variant.py, r04i_config_search_*.txt) moved
+//     4608 to 12.16.24 (-5 %) and 6144 to 16.16.24 (-10 %): R2 = 16 halves stage 2's twiddle table against R2 = 24 / 32.  Everything
+//     else it tried was within noise (+-3 %) or slower (up to +90 %); the list is what survived.
 //   * Radix orders at 4224 (round 2): 8.24.22 25.0 us per map, 12.16.22 25.6, 11.16.24 27.3, 16.12.22 28.0: small R1, fat stage 3.
 // Three groups, one translation unit each per kernel family (kernels_rows*_g?.hip): build time only.
 #define FC_FAST_ROW_CONFIGS_G0(X)   \
@@ -46,18 +49,18 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(7040, 10, 32, 22, 640, 2, 3)  \
     X(7040, 10, 32, 22, 640, 2, 6)  \
     X(7040, 10, 32, 22, 640, 2, 32) \
-    X(6144, 8, 32, 24, 256, 1, 3)   \
-    X(6144, 8, 32, 24, 256, 1, 6)   \
-    X(6144, 8, 32, 24, 256, 1, 32)  \
+    X(6144, 16, 16, 24, 256, 1, 3)  \
+    X(6144, 16, 16, 24, 256, 1, 6)  \
+    X(6144, 16, 16, 24, 256, 1, 16) \
     X(5632, 16, 16, 22, 256, 1, 3)  \
     X(5632, 16, 16, 22, 256, 1, 16) \
     X(5120, 8, 32, 20, 256, 1, 4)   \
     X(5120, 8, 32, 20, 256, 1, 7)   \
     X(5120, 8, 32, 20, 256, 1, 32)
 #define FC_FAST_ROW_CONFIGS_G1(X)   \
-    X(4608, 8, 24, 24, 192, 1, 3)   \
-    X(4608, 8, 24, 24, 192, 1, 6)   \
-    X(4608, 8, 24, 24, 192, 1, 24)  \
+    X(4608, 12, 16, 24, 192, 1, 3)  \
+    X(4608, 12, 16, 24, 192, 1, 6)  \
+    X(4608, 12, 16, 24, 192, 1, 16) \
     X(4224, 8, 24, 22, 192, 1, 3)   \
     X(4224, 8, 24, 22, 192, 1, 6)   \
     X(4224, 8, 24, 22, 192, 1, 24)  \
@@ -217,11 +220,14 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 // length 2M along h), T columns per tile, NT = R1 * R2 * T threads (one stage-3 butterfly per thread).  T = 16 (full 128-byte lines of
 // the tiled intermediate) while 16 columns fit the LDS (M <= 1056), 8 up to M = 2304, 4 above.  The forward column kernel
 // (fast_cols_fwd.hpp) runs the same configurations.
-//   * cfg3: M = 2112 = 8.12.22, 8 columns, 768 threads (4 columns / 384 threads, two workgroups per CU, measured 47.8 against 36.1 us
-//     per map in round 1); cfg5: 1056 = 6.8.22; cfg2: 576 = 6.8.12; cfg1: 144 = 4.6.6.
+//   * cfg3: M = 2112 = 6.16.22, 8 columns, 768 threads (8.12.22 until the round-4 search: 6.16.22 is 4 % faster, roofline fraction
+//     0.68 -> 0.71; 4 columns / 384 threads, two workgroups per CU, measured 47.8 against 36.1 us per map in round 1); cfg5: 1056 =
+//     6.8.22; cfg2: 576 = 6.8.12; cfg1: 144 = 4.6.6.
 //   * Round 4: the R3 = 16 / 24 forms were replaced (stage-3 bank conflicts, see the row list): output kernel -2 ... -15 % for eleven
 //     lengths (r04h_row_and_column_configs_ab.txt); 1024-thread workgroups (16 waves, <= 128 VGPRs) where R3 = 10 / 12 / 18 needs
 //     them.  M = 1152 as 8.8.18 / T = 16, 576 as 4.8.18 and 288 as 6.8.6 measured no better than the listed forms.
+//   * The same search (r04i_config_search_*.txt): M = 3520 as 10.16.22 (-4 %), 1760 as 5.16.22 (-6 %); 1056 as 3.16.22, 1152 as 12.8.12,
+//     576 as 3.16.12 / 4.12.12, 1408 as 4.16.22 within noise over three repetitions and left alone.
 //   * M = 2080 = 8.10.26 and 544 = 2.17.16: the cfg4 / cfg2 windows' own kernels (exact_window plans); 2080 spills 12 registers.
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
@@ -234,7 +240,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(2112, 6, 16, 22, 8, 768)    \
     X(2080, 8, 10, 26, 8, 640)    \
     X(1920, 8, 12, 20, 8, 768)    \
-    X(1760, 8, 10, 22, 8, 640)
+    X(1760, 5, 16, 22, 8, 640)
 #define FC_FAST_COL_CONFIGS_G1(X) \
     X(1536, 8, 16, 12, 8, 1024)    \
     X(1408, 8, 8, 22, 8, 512)    \
