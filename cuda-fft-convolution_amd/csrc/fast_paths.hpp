@@ -36,8 +36,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //     14, 18, 22, 26.  The R3 = 16 forms went (r04h_row_and_column_configs_ab.txt: rows -11 ... -25 %); 4608 as 8.32.18 and 1152 as
 //     8.8.18 x4 measured SLOWER than the R3 = 24 / 12 forms -- bank conflicts are one term, not the whole cost.
 //   * A search over every admissible (R1, R2, R3, threads) of each length (tools/config_variant.py, r04i_config_search_*.txt) moved
-//     4608 to 12.16.24 (-5 %) and 6144 to 16.16.24 (-10 %): R2 = 16 halves stage 2's twiddle table against R2 = 24 / 32.  Everything
-//     else it tried was within noise (+-3 %) or slower (up to +90 %); the list is what survived.
+//     4608 to 12.16.24 (-5 %), 6144 to 16.16.24 (-10 %), 3072 to 16.16.12 (-9 %) and 2560 to 16.16.10 (-14 %): a power-of-two stage 2
+//     of 16 points against 24 / 32.  No rule came out of it -- 5120 as 16.16.20 is 6 % SLOWER than 8.32.20, 4608 as 16.16.18 14 % slower
+//     than 12.16.24 -- and everything else it tried was within noise (+-3 %) or slower (up to +90 %); the list is what survived.
 //   * Radix orders at 4224 (round 2): 8.24.22 25.0 us per map, 12.16.22 25.6, 11.16.24 27.3, 16.12.22 28.0: small R1, fat stage 3.
 // Three groups, one translation unit each per kernel family (kernels_rows*_g?.hip): build time only.
 #define FC_FAST_ROW_CONFIGS_G0(X)   \
@@ -70,12 +71,12 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(3840, 8, 24, 20, 192, 1, 24)  \
     X(3520, 10, 16, 22, 192, 1, 3)  \
     X(3520, 10, 16, 22, 192, 1, 16) \
-    X(3072, 8, 32, 12, 256, 1, 6)   \
-    X(3072, 8, 32, 12, 256, 1, 32)  \
+    X(3072, 16, 16, 12, 256, 1, 6)  \
+    X(3072, 16, 16, 12, 256, 1, 16) \
     X(2816, 8, 16, 22, 192, 1, 3)   \
     X(2816, 8, 16, 22, 192, 1, 16)  \
-    X(2560, 8, 32, 10, 256, 1, 7)   \
-    X(2560, 8, 32, 10, 256, 1, 32)
+    X(2560, 16, 16, 10, 256, 1, 7)  \
+    X(2560, 16, 16, 10, 256, 1, 16)
 #define FC_FAST_ROW_CONFIGS_G2(X)   \
     X(2304, 8, 16, 18, 256, 2, 4)   \
     X(2304, 8, 16, 18, 256, 2, 16)  \
