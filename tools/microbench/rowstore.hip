@@ -4,6 +4,7 @@
 // row 270 KB apart), streaming stores, in the kernel's order (3 rounds x 8 stores, butterfly outputs 33 tiles
 // apart).  Variants: (1) the same with 16 bytes per lane; (2) two adjacent rows per workgroup (256-byte
 // pieces); (3) a row-major intermediate (33.8 KB contiguous per row).
+// (4) / (5): an intermediate of tile width 4 (Y[map][w/4][row][4]) written by one row / two adjacent rows per workgroup.
 // Standalone: hipcc --offload-arch=gfx950 -O3 rowstore.hip -o rowstore
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -54,6 +55,34 @@ __global__ void __launch_bounds__(NT) k_store(f2* __restrict__ Y, int maps) {
                     }
                 }
             }
+        } else if (MODE == 4) {   // tile width 4 (Y[map][w/4][row][4]): lane writes columns 2q, 2q+1, two lanes = one 32-byte piece
+            for (int r = 0; r < 2; r++) {
+                const int q = t + NT * r;
+                if (q < 264) {
+                    const int j = 2 * q;
+                    f4 w = {v.x, v.y, v.x, v.y};
+#pragma unroll
+                    for (int a = 0; a < 8; a++) {
+                        const int jj = j + a * 528;
+                        __builtin_nontemporal_store(w, reinterpret_cast<f4*>(yb + ((size_t)(jj >> 2) * ROWS + row) * 4 + (jj & 3)));
+                    }
+                }
+            }
+        } else if (MODE == 5) {   // tile width 4, workgroup owns rows 2*row, 2*row+1: four lanes = one 64-byte piece
+            for (int r = 0; r < 3; r++) {
+                const int u = t + NT * r;      // 0..527: (pair of columns q, which row)
+                if (u < 528) {
+                    const int q = (u >> 2) * 2 + (u & 1), rr = (u >> 1) & 1, rw = 2 * row + rr;
+                    f4 w = {v.x, v.y, v.x, v.y};
+                    if (rw < NROW) {
+#pragma unroll
+                        for (int a = 0; a < 8; a++) {
+                            const int jj = 2 * q + a * 528;
+                            __builtin_nontemporal_store(w, reinterpret_cast<f4*>(yb + ((size_t)(jj >> 2) * ROWS + rw) * 4 + (jj & 3)));
+                        }
+                    }
+                }
+            }
         } else {                  // row-major: row contiguous
             f2* p0 = yb + (size_t)row * FW;
             for (int r = 0; r < 3; r++) {
@@ -93,5 +122,7 @@ int main() {
     run("16 B/lane", k_store<1>, dim3(NROW, maps / WALK));
     run("two adjacent rows per workgroup (256-B pieces)", k_store<2>, dim3((NROW + 1) / 2, maps / WALK));
     run("row-major intermediate (contiguous rows)", k_store<3>, dim3(NROW, maps / WALK));
+    run("tile width 4, one row per workgroup (32-B pieces)", k_store<4>, dim3(NROW, maps / WALK));
+    run("tile width 4, two adjacent rows per workgroup (64-B pieces)", k_store<5>, dim3((NROW + 1) / 2, maps / WALK));
     return 0;
 }
