@@ -536,6 +536,7 @@ def main():
     plan = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream, options=plan_opts)
     info = plan.info
     P = info.fft_h * info.fft_w
+    nblk = max(1, plan.get_option("blockwise"))      # > 1: the plan runs blocks of a shorter transform (a launch covers 1 / nblk of its maps)
     if args.batch_maps:
         plan.set_option("batch_maps", args.batch_maps)
     if args.rows_group:
@@ -788,7 +789,7 @@ def main():
             p = prof[name]
             if p["launches"]:
                 avg_ms = p["ms"] / p["launches"]
-                units = p["units"] / p["launches"]
+                units = p["units"] / p["launches"] / nblk
                 per[name] = {"avg_ms": avg_ms, "units_per_launch": units,
                              "gbps": ab[name] * units / (avg_ms * 1e-3) / 1e9}
         for name in list(per):
@@ -796,7 +797,7 @@ def main():
             if lv and lv["launches"]:
                 # the figures of the hot kernels (and so the roofline) use the launches of the timed region itself
                 avg_ms = lv["ms"] / lv["launches"]
-                units = lv["units"] / lv["launches"]
+                units = lv["units"] / lv["launches"] / nblk
                 per[name] = {"avg_ms": avg_ms, "units_per_launch": units, "gbps": ab[name] * units / (avg_ms * 1e-3) / 1e9,
                              "separate_pass_avg_ms": per[name]["avg_ms"],
                              "timed_in": "the timed region (%d launches)" % lv["launches"]}
@@ -838,6 +839,7 @@ def main():
                                       total_maps, info.fft_h, info.fft_w,
                                       "image-sharded" if streamed else "filter-sharded"),
                        "transform": [info.transform_h, info.transform_w],
+                       "blocks": nblk if nblk > 1 else None,      # overlap-save blocks of that transform (include/fftconv.h: blockwise)
                        "filters_total": nf_total,
                        "filters_per_gpu": nf if streamed else -(-nf_total // world),
                        "kernels": ("uploaded from pinned host memory inside every step (SURVEY 8(d)): %d uploads in the %d timed steps, %s"

@@ -60,7 +60,12 @@ struct FastColsArgs {
     size_t out_kernel_stride;
     int fft_h, fft_w;        // output window: fft_h <= 2M (rows beyond it are cropped), fft_w % T == 0,
                              // every column < fft_w exists in Y
-    int tiles_per_kernel;    // fft_w / T
+    // The window may be a sub-rectangle of the transform (overlap-save blocks of a block-wise plan, fftconv_api.cpp:
+    // the first rows / columns of a block's circular result are wrapped and belong to nobody): rows [h_lo, fft_h) of
+    // columns [w_first, w_first + tiles_per_kernel * T) are stored, row h of column w at out + w * out_pitch + h (the
+    // host offsets `out` so that this lands in the full map).  Plain plans: h_lo = 0, w_first = 0, out_pitch = fft_h.
+    int h_lo, w_first, out_pitch;   // h_lo even, w_first % T == 0, out_pitch even
+    int tiles_per_kernel;    // stored columns / T
     int ntiles;              // tiles_per_kernel * kernels in this launch
     int y_tiled;             // 1: Y is tiled [w / TL][row][TL] with the rows of bins (k, M-k) adjacent (rows 2k, 2k+1;
                              //    M+2 rows per tile): merged in registers on the way into LDS.  0: row-major [i][y_pitch]
@@ -180,7 +185,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     auto issue_gather = [&](int t, State& st, int tile, auto part_, [[maybe_unused]] int c_lo, [[maybe_unused]] int c_hi) {
         constexpr int part = decltype(part_)::value;
         const int kernel = tile / g.tiles_per_kernel;
-        const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
+        const int w0 = g.w_first + (tile - kernel * g.tiles_per_kernel) * T;
         if constexpr (PLAND) {   // rows 2p, 2p+1 = bins (p, M-p); one thread takes both for two columns
             const int tw = 1 << g.y_tile_shift;
             const c32* Yt = g.Y + (size_t)kernel * g.y_kernel_stride + (size_t)(w0 >> g.y_tile_shift) * g.y_tile_elems + (w0 & (tw - 1));
@@ -298,7 +303,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         const int tile = tile_of(it);
         if (tile >= n_total) break;
         const int kernel = tile / g.tiles_per_kernel;
-        const int w0 = (tile - kernel * g.tiles_per_kernel) * T;
+        const int w0 = g.w_first + (tile - kernel * g.tiles_per_kernel) * T;
         const int next = tile_of(it + 1);
         if constexpr (SLICED) { cur_lo = cols_lo(it); cur_hi = cols_hi(it); nxt_lo = cols_lo(it + 1); nxt_hi = cols_hi(it + 1); }
         FC_COLS_STAMP(0);
@@ -401,7 +406,8 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         FC_COLS_STAMP(3);
         // C4: inverse stage 1 straight to the map: out[w][2n], out[w][2n+1] = re, im of z[n]
         float* out = g.out + (size_t)kernel * g.out_kernel_stride;
-        const int nout = g.fft_h >> 1;   // complex pairs per output column
+        const int pair_lo = g.h_lo >> 1;                                 // complex pairs [pair_lo, pair_lo + nout) of a column are stored
+        const unsigned nout = (unsigned)((g.fft_h - g.h_lo) >> 1);
         ctx.phase([&](int t, State&) {
 #if !FC_COLS_NO_PREWAIT
             // the next tile's gather (issued in C1) has had two stages to arrive: take it off the
@@ -426,11 +432,11 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                         v[c] = cmulc(p[c * m1], pw[c]);
                     });
                     Dft<R1, +1>::run(v);
-                    c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.fft_h);
+                    c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.out_pitch);
                     static_for<0, R1>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
                         if constexpr (FC_COLS_DBG & 8) { if (v[a].x == 1.2345e-30f) o[j + a * m1] = v[a]; }
-                        else if (j + a * m1 < nout) FC_STREAM_STORE(&o[j + a * m1], v[a]);
+                        else if ((unsigned)(j + a * m1 - pair_lo) < nout) FC_STREAM_STORE(&o[j + a * m1], v[a]);
                     });
                 }
             }

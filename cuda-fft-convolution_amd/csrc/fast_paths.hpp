@@ -293,6 +293,32 @@ inline double fast_cols_factor(int M, int) {
     return 0.45;
 }
 
+// Measured cost of the two hot kernels per point of their transforms, picoseconds (profiles/r04k_cost_per_point_by_length.txt:
+// the multi-map row kernel per point of a spectrum row, the output kernel per complex point of a stored column; one MI355X,
+// 63 x 63 kernels, 16-64 maps per launch).  The block-wise planner (fftconv_api.cpp: choose_save_tiling) weighs block
+// transforms against each other and against one pass with them; only the ratios matter.
+inline double fast_rows_ps(int L) {
+    switch (L) {
+        case 1152: return 2.52; case 1344: return 2.71; case 1536: return 2.21; case 1760: return 2.53; case 1920: return 2.39;
+        case 2112: return 2.41; case 2304: return 2.23; case 2560: return 2.38; case 2816: return 2.43; case 3072: return 2.12;
+        case 3520: return 2.55; case 3840: return 2.42; case 4224: return 2.39; case 4608: return 2.42; case 5120: return 2.38;
+        case 5632: return 2.40; case 6144: return 2.38; case 7040: return 2.86; case 7680: return 2.62; case 8448: return 2.78;
+        case 1088: case 4160: return 2.9;
+        default: return 2.7;             // the small lengths (launch-bound at their own sizes)
+    }
+}
+inline double fast_cols_ps(int M) {
+    switch (M) {
+        case 576: return 2.94; case 672: return 2.84; case 768: return 2.97; case 880: return 3.06; case 960: return 2.84;
+        case 1056: return 2.94; case 1152: return 2.89; case 1280: return 2.78; case 1408: return 3.01; case 1536: return 2.83;
+        case 1760: return 2.95; case 1920: return 2.92; case 2112: return 2.80; case 2304: return 2.80;
+        case 2560: return 3.76; case 2816: return 3.66; case 3072: return 3.62; case 3520: return 3.70; case 3840: return 3.69;
+        case 4224: return 3.67;
+        case 544: case 2080: return 3.3;
+        default: return 3.1;
+    }
+}
+
 // Forward column kernel (fast_cols_fwd.hpp): same configurations; NZ2 = 3 (pruned, short kernels)
 // or R2 (any input length).  run.template go<Cfg, NZ2>().
 template <int G, class Runner>

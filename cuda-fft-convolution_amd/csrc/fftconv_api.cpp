@@ -326,8 +326,18 @@ int rows_threads(const Geometry& g) {
 
 struct TiledState;
 
+// Where the block plan of an overlap-save block-wise plan stores its maps (set around each run by tiled_convolve): rows
+// [h_lo, h_hi) of columns [w_first, w_first + ncols) of the block's circular result, row h of column w of map j at
+// base + j * map_stride + w * pitch + h -- the block's rectangle of the full maps (base is offset accordingly).
+struct OutWindow {
+    float* base;
+    size_t map_stride;
+    int pitch, h_lo, h_hi, w_first, ncols;
+};
+
 struct fftconv_plan {
-    TiledState* tiled = nullptr;   // block-wise (overlap-add) plan: sizes beyond one LDS-resident pass (see TiledState)
+    TiledState* tiled = nullptr;   // block-wise plan: sizes beyond one LDS-resident pass, or large sizes that run faster in blocks (see TiledState)
+    const OutWindow* win = nullptr;   // block plan of an overlap-save plan: the output kernel writes this window, whatever the sink says
     Geometry g;
     Tables t;
     DeviceTables d;
@@ -756,7 +766,9 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
                sink.packed ? "packed device output" : sink.location == FFTCONV_HOST ? "host output" : "device output");   // :68
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
     if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
-    const bool staged = (sink.packed == nullptr);
+    const OutWindow* win = p->win;
+    if (win && !g.fast_cols.ok) return fail(FFTCONV_ERR_INVALID_ARG, "an output window needs the specialised output kernel");
+    const bool staged = (sink.packed == nullptr) && !win;
     // host output: two staging buffers, the copy-out of batch b overlaps the compute of batch b + 1
     // ... for maps of at least host_min_kb (1 MiB).  Smaller ones leave by blocking copies on the plan's stream:
     // the copy threads buy them nothing (a one-shot call would start and join them for a few hundred KB), and
@@ -778,7 +790,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     if (streamed)
         if (int rc = ring_ensure(p)) return rc;
     if (p->Y.fresh) {   // before anything is written into it: the tuner may keep another allocation
-        if (p->opt_tune_placement > 1) {
+        if (p->opt_tune_placement > 1 && !win) {
             const bool direct = !cropped && !staged;   // the output kernel writes straight into the caller's packed buffer
             float* first_obase = cropped ? p->O.p : (staged ? stage.p : sink.packed);
             if (int rc = tune_intermediate_placement(p, direct ? n : std::min(nbY, n), nbY, first_obase, direct ? oe : 0)) return rc;
@@ -815,7 +827,8 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
             }
             if (int rc = p->prof_end()) return rc;
             const int buf = streamed ? (batch & 1) : 0;
-            float* dest = staged ? stage.p + (size_t)buf * nbY * oe : sink.packed + (size_t)(a0 + y0) * oe;   // where the maps of this batch go
+            float* dest = win ? win->base + (size_t)(a0 + y0) * win->map_stride                               // where the maps of this batch go
+                          : staged ? stage.p + (size_t)buf * nbY * oe : sink.packed + (size_t)(a0 + y0) * oe;
             float* obase = cropped ? p->O.p : dest;                                                            // where the output kernel writes
             if (streamed && batch >= 2) {   // staging buffer `buf` still holds batch - 2 until its copy-out is over
                 if (p->ring->nslots == 0) p->ring->wait_staging_free(buf);
@@ -823,7 +836,11 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
             }
             if (int rc = p->prof_begin(PK_OUT_COLS, ny)) return rc;
             if (g.fast_cols.ok) {
-                FastColsArgs fa = fast_cols_args(g, p->d, p->Y.p, obase, g.map_elems(), ny);
+                FastColsArgs fa = fast_cols_args(g, p->d, p->Y.p, obase, win ? win->map_stride : g.map_elems(), ny);
+                if (win) {
+                    fa.h_lo = win->h_lo; fa.fft_h = win->h_hi; fa.w_first = win->w_first; fa.out_pitch = win->pitch;
+                    fa.tiles_per_kernel = win->ncols / g.fast_cols.T; fa.ntiles = fa.tiles_per_kernel * ny;
+                }
                 HIP_TRY(launch_fast_cols(g.M, g.fast_cols.T, fa, p->num_cus, p->stream));
             } else {
                 ColsC2RArgs ca = cols_c2r_args(g, p->t, p->d, p->Y.p, obase, g.map_elems());
@@ -885,20 +902,33 @@ int check_thread_size(const double* thread_size, int n_thread_size) {
 
 
 // Block-wise plans: sizes whose padded window does not fit a single LDS-resident pass (about 20 000 samples along
-// w), or any size when fftconv_plan_options.max_transform forces it.  Overlap-add: the image is cut into blocks of
-// Bh x Bw samples, every block is convolved by an ordinary plan (block + MAX_KERNEL - 1 <= 4224, the fastest
-// specialised length), and the block results are summed on the device into the full FFT_H x FFT_W maps at their
-// offsets (convolution is linear and the blocks partition the image).  The block spectra are computed once per
-// image and kept (the plan's "spectrum" is their concatenation, so the multi-device copy / broadcast works
-// unchanged); kernels are processed in chunks that fit a few GiB of device maps.  The reference has no such limit
-// (cuFFT plans any size: src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98); kernels larger than MAX_KERNEL
-// cannot be folded block-wise and are rejected.
+// w), any size when fftconv_plan_options.max_transform forces it, and large one-pass sizes that run faster in blocks
+// (blocks_preferred below).  Two forms:
+//   overlap-save (the default path's specialised kernels exist for the block transform): the block plan is CYCLIC over
+//     Lh x Lw samples (PlanTuning::cyclic).  Block (by, bx) is the image's rows [by * Bh - Sh, by * Bh + Bh) -- Bh = Lh - Sh
+//     new rows behind Sh >= MAX_KERNEL_H - 1 rows of history, zeros outside the image -- and columns likewise; of its
+//     circular result the first Sh rows / Sw columns are wrapped and belong to nobody, the rest IS rows [by * Bh, by * Bh + Bh)
+//     of the maps, and the output kernel stores it there (OutWindow): no block maps, no summing pass, every element of the
+//     maps written once.  A dimension one block covers has no history (Sh = 0, Lh >= FFT_H: plain zero padding).
+//   overlap-add (otherwise): blocks of Bh x Bw samples, zero-padded by an ordinary plan, the block results summed on the
+//     device into the full maps at their offsets (convolution is linear and the blocks partition the image).
+// The block spectra are computed once per image and kept (the plan's "spectrum" is their concatenation, so the
+// multi-device copy / broadcast works unchanged); kernels are processed in chunks that fit a few GiB of device maps.
+// The reference has no such limit (cuFFT plans any size: src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98);
+// kernels larger than MAX_KERNEL cannot be folded block-wise and are rejected.
 }  // namespace
+
+int plan_create_internal(fftconv_plan** plan, int data_h, int data_w, int feature_dim, int max_kernel_h, int max_kernel_w, int gpu_id,
+                         void* hip_stream, const fftconv_plan_options* options, bool cyclic);
 
 struct TiledState {
     fftconv_plan* sub = nullptr;     // the block plan (an ordinary plan on the same stream)
     int H = 0, W = 0, F = 0, mkh = 0, mkw = 0;
     int Bh = 0, Bw = 0, nbh = 0, nbw = 0, nblk = 0, FH = 0, FW = 0;
+    // overlap-save (see the comment above): the block plan is cyclic over Lh x Lw samples, block (by, bx) reads the image rows
+    // [by * Bh - Sh, by * Bh + Bh) and stores the rows [by * Bh, by * Bh + Bh) of the maps straight from the output kernel
+    bool save = false;
+    int Lh = 0, Lw = 0, Sh = 0, Sw = 0;
     size_t spec_elems = 0;           // c32 per block spectrum
     DevBuf<c32> specs;               // block spectra, [block][spec_elems] (own buffer)
     c32* specs_x = nullptr;          // caller-owned instead (fftconv_plan_use_spectrum_buffer)
@@ -922,36 +952,123 @@ int tiled_unsupported(const char* what) {
     return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "%s is not available on a block-wise plan (the padded size does not fit one transform pass)", what);
 }
 
+// ---- overlap-save blocks: which block transform, how many blocks ----
+// One dimension: transform length L (a length with specialised kernels), n blocks, S history samples in front of each
+// block (S = 0 and L >= window when one block covers the dimension; else S = MAX_KERNEL - 1 rounded up to the layout tile).
+struct DimChoice { int L = 0, n = 0, S = 0; };
+struct SaveTiling {
+    bool ok = false;
+    DimChoice h, w;
+    double ps = 0;    // estimated time per map, picoseconds
+};
+
+// estimated time per map of (h, w): the row kernel transforms every spectrum row of every block, the output kernel the
+// stored columns only (fast_paths.hpp: measured cost per point of each specialised length; rows_ps / cols_ps < 0: those).
+// Every block adds launches, its kernel-column pass and the gaps between them: ~25 us per block and launch, taken over
+// 16 maps (profiles/r04k_blocks_vs_one_pass.txt: 18 blocks of 1344 x 3072 lose to one pass of 7680 x 7680 by that alone).
+constexpr double kBlockOverheadPs = 1.6e6;
+double tiling_ps(const DimChoice& h, const DimChoice& w, int FW, double rows_ps = -1.0, double cols_ps = -1.0) {
+    const double rows = (double)h.n * w.n * (h.L / 2 + 1) * w.L * (rows_ps < 0 ? fast_rows_ps(w.L) : rows_ps);
+    const double cols = (double)h.n * FW * (h.L / 2) * (cols_ps < 0 ? fast_cols_ps(h.L / 2) : cols_ps);
+    return rows + cols + (h.n * w.n > 1 ? kBlockOverheadPs * h.n * w.n : 0.0);
+}
+
+std::vector<DimChoice> dim_choices(int window, int mk, bool w_dim, int mkw, int limit) {
+    std::vector<DimChoice> v;
+    const int S = round_up(std::max(0, mk - 1), Geometry::y_tile_w);
+    for (int L = 32; L <= limit; L += 32) {
+        const bool have = w_dim ? fast_rows_lookup(L, mkw).ok : fast_cols_lookup(L / 2).ok;
+        if (!have || L < mk) continue;
+        DimChoice c;
+        c.L = L;
+        if (L >= window) { c.n = 1; c.S = 0; }
+        else if (L - S >= Geometry::y_tile_w) { c.S = S; c.n = (window + (L - S) - 1) / (L - S); }
+        else continue;
+        v.push_back(c);
+    }
+    return v;
+}
+
+// the cheapest overlap-save tiling of the window FH x FW within transforms of at most `limit` samples
+SaveTiling choose_save_tiling(int FH, int FW, int mkh, int mkw, int limit) {
+    SaveTiling best;
+    const std::vector<DimChoice> hs = dim_choices(FH, mkh, false, mkw, limit), ws = dim_choices(FW, mkw, true, mkw, limit);
+    for (const DimChoice& h : hs)
+        for (const DimChoice& w : ws) {
+            if (h.n > 1 && (h.L - h.S) % Geometry::y_tile_w) continue;
+            const double ps = tiling_ps(h, w, FW);
+            if (!best.ok || ps < best.ps) { best.ok = true; best.h = h; best.w = w; best.ps = ps; }
+        }
+    return best;
+}
+
+// a plan that fits one pass: do blocks of a shorter transform beat it?  Only the long transforms can lose: the 4-column
+// output kernels (M >= 2560), the two-rows-per-CU row kernels (>= 7040 points), and lengths beyond the specialised ones
+// (generic kernels, ~2.5 x the cost per point).  The model is good to ~5 %: blocks need a predicted 3 %.
+bool blocks_preferred(const Geometry& g, const fftconv_plan_options* options) {
+    if (g.path_mode != 2) return false;
+    const bool fast = g.fast_rows.ok && g.fast_cols.ok && g.y_tiled();
+    if (fast && g.Lh < 5120 && g.Lw < 7040) return false;
+    if (!fast && g.Lh <= 8448 && g.Lw <= 8448) return false;      // small or oddly sized: not what blocks are for
+    int limit = 4608;
+    if (options && options->struct_size >= kOptionsMinSize && options->max_transform > 0) limit = std::min(limit, options->max_transform);
+    const SaveTiling t = choose_save_tiling(g.fft_h, g.fft_w, g.max_kh, g.max_kw, limit);
+    if (!t.ok || t.h.n * t.w.n < 2) return false;
+    DimChoice h1, w1;
+    h1.L = g.Lh; h1.n = 1; w1.L = g.Lw; w1.n = 1;
+    const double one_pass = tiling_ps(h1, w1, g.fft_w, g.fast_rows.ok ? -1.0 : 6.0, g.fast_cols.ok ? -1.0 : 7.5);
+    return t.ps < 0.97 * one_pass;
+}
+
 // creates the block plan of a tiled plan; FFTCONV_ERR_UNSUPPORTED_SIZE if no block shape works
 int tiled_create(fftconv_plan* p, int H, int W, int F, int mkh, int mkw, void* hip_stream, const fftconv_plan_options* options) {
     int limit = 4224;
-    if (options && options->struct_size >= kOptionsMinSize && options->max_transform > 0) limit = std::min(limit, options->max_transform);
-    const int full_h = limit - mkh + 1, full_w = limit - mkw + 1;
-    if (full_h < 1 || full_w < 1)
-        return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "kernels up to %dx%d are too large for the block-wise path", mkh, mkw);
+    const bool limited = options && options->struct_size >= kOptionsMinSize && options->max_transform > 0;
+    if (limited) limit = std::min(limit, options->max_transform);
     TiledState* ts = new (std::nothrow) TiledState();
     if (!ts) return fail(FFTCONV_ERR_ALLOC, "out of host memory");
     fftconv_plan_options sub_opts = {};
     if (options && options->struct_size >= kOptionsMinSize) memcpy(&sub_opts, options, std::min(sizeof(sub_opts), options->struct_size));
     sub_opts.struct_size = sizeof(sub_opts);
     sub_opts.blockwise = 1;          // the block plan itself is a single pass
-    // fewest blocks first: tile only the dimension(s) that need it
-    const int cand[3][2] = {{H, std::min(W, full_w)}, {std::min(H, full_h), W}, {std::min(H, full_h), std::min(W, full_w)}};
-    int rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
-    for (int c = 0; c < 3 && !ts->sub; c++) {
-        ts->Bh = cand[c][0]; ts->Bw = cand[c][1];
-        rc = fftconv_plan_create_ex(&ts->sub, ts->Bh, ts->Bw, F, mkh, mkw, p->gpu_id, hip_stream, &sub_opts);
-        if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) { delete ts; return rc; }
-    }
-    if (!ts->sub) { delete ts; return rc; }
     ts->H = H; ts->W = W; ts->F = F; ts->mkh = mkh; ts->mkw = mkw;
-    ts->nbh = (H + ts->Bh - 1) / ts->Bh; ts->nbw = (W + ts->Bw - 1) / ts->Bw; ts->nblk = ts->nbh * ts->nbw;
     ts->FH = fft_size16(H + mkh - 1); ts->FW = fft_size16(W + mkw - 1);
+    int rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
+    // overlap-save first: needs the specialised kernels of the default path for the block transform
+    if (tuning_from(options).path_mode == 2) {
+        const SaveTiling t = choose_save_tiling(ts->FH, ts->FW, mkh, mkw, limited ? limit : 4608);
+        if (t.ok) {
+            rc = plan_create_internal(&ts->sub, t.h.L, t.w.L, F, mkh, mkw, p->gpu_id, hip_stream, &sub_opts, true);
+            if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) { delete ts; return rc; }
+            if (ts->sub) {
+                ts->save = true;
+                ts->Lh = t.h.L; ts->Lw = t.w.L; ts->Sh = t.h.S; ts->Sw = t.w.S;
+                ts->Bh = t.h.L - t.h.S; ts->Bw = t.w.L - t.w.S; ts->nbh = t.h.n; ts->nbw = t.w.n;
+            }
+        }
+    }
+    if (!ts->sub) {                  // overlap-add over ordinary (zero-padded) block plans
+        const int full_h = limit - mkh + 1, full_w = limit - mkw + 1;
+        if (full_h < 1 || full_w < 1) {
+            delete ts;
+            return fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "kernels up to %dx%d are too large for the block-wise path", mkh, mkw);
+        }
+        // fewest blocks first: tile only the dimension(s) that need it
+        const int cand[3][2] = {{H, std::min(W, full_w)}, {std::min(H, full_h), W}, {std::min(H, full_h), std::min(W, full_w)}};
+        for (int c = 0; c < 3 && !ts->sub; c++) {
+            ts->Bh = cand[c][0]; ts->Bw = cand[c][1];
+            rc = fftconv_plan_create_ex(&ts->sub, ts->Bh, ts->Bw, F, mkh, mkw, p->gpu_id, hip_stream, &sub_opts);
+            if (rc && rc != FFTCONV_ERR_UNSUPPORTED_SIZE) { delete ts; return rc; }
+        }
+        if (!ts->sub) { delete ts; return rc; }
+        ts->nbh = (H + ts->Bh - 1) / ts->Bh; ts->nbw = (W + ts->Bw - 1) / ts->Bw;
+    }
+    ts->nblk = ts->nbh * ts->nbw;
     ts->spec_elems = ts->sub->g.spectrum_elems();
     p->tiled = ts;
     Geometry& g = p->g;             // what fftconv_plan_get_info reports
     g = ts->sub->g;
-    g.H = H; g.W = W; g.fft_h = ts->FH; g.fft_w = ts->FW; g.exact_window = false;
+    g.H = H; g.W = W; g.max_kh = mkh; g.max_kw = mkw; g.fft_h = ts->FH; g.fft_w = ts->FW; g.exact_window = false;
     p->num_cus = ts->sub->num_cus;
     return 0;
 }
@@ -964,8 +1081,36 @@ int tiled_set_image(fftconv_plan* p, const float* data, int location) {
         if (int rc = ts->specs.ensure(ts->spec_total())) return rc;
     const int H = ts->H, W = ts->W, F = ts->F, Bh = ts->Bh, Bw = ts->Bw;
     FC_VERBOSE(p, "Data size: h=%d, w=%d, f=%d", H, W, F);
-    FC_VERBOSE(p, "FFT size: h=%d, w=%d (block-wise: %d x %d blocks of %d x %d samples, block transforms %d x %d)", ts->FH, ts->FW, ts->nbh, ts->nbw,
-               Bh, Bw, sub->g.Lh, sub->g.Lw);
+    FC_VERBOSE(p, "FFT size: h=%d, w=%d (block-wise, %s: %d x %d blocks of %d x %d samples, block transforms %d x %d)", ts->FH, ts->FW,
+               ts->save ? "overlap-save" : "overlap-add", ts->nbh, ts->nbw, Bh, Bw, sub->g.Lh, sub->g.Lw);
+    if (ts->save) {
+        // block (by, bx) of the block plan's Lh x Lw samples: image rows [by * Bh - Sh, by * Bh + Bh) (zeros outside the image)
+        const int Lh = ts->Lh, Lw = ts->Lw;
+        if (location == FFTCONV_HOST) ts->hblk.resize((size_t)Lh * Lw * F);
+        else if (int rc = ts->blk.ensure((size_t)Lh * Lw * F)) return rc;
+        for (int b = 0; b < ts->nblk; b++) {
+            const int y0 = (b % ts->nbh) * Bh - ts->Sh, x0 = (b / ts->nbh) * Bw - ts->Sw;       // image coordinates of the block's sample (0, 0)
+            const int ys = std::max(0, y0), ye = std::min(H, y0 + Lh), xs = std::max(0, x0), xe = std::min(W, x0 + Lw);
+            const bool any = ye > ys && xe > xs;
+            if (int rc = fftconv_plan_use_spectrum_buffer(sub, ts->spec_base() + (size_t)b * ts->spec_elems, ts->spec_elems * sizeof(c32))) return rc;
+            if (location == FFTCONV_HOST) {
+                std::fill(ts->hblk.begin(), ts->hblk.end(), 0.f);
+                for (int f = 0; f < F && any; f++)
+                    for (int x = xs; x < xe; x++)
+                        memcpy(&ts->hblk[((size_t)f * Lw + (x - x0)) * Lh + (ys - y0)], &data[((size_t)f * W + x) * H + ys], (size_t)(ye - ys) * sizeof(float));
+                if (int rc = fftconv_plan_set_image(sub, ts->hblk.data(), FFTCONV_HOST)) return rc;   // synchronous for host input
+            } else {
+                HIP_TRY(hipMemsetAsync(ts->blk.p, 0, (size_t)Lh * Lw * F * sizeof(float), sub->stream));
+                for (int f = 0; f < F && any; f++)
+                    HIP_TRY(hipMemcpy2DAsync(ts->blk.p + ((size_t)f * Lw + (xs - x0)) * Lh + (ys - y0), (size_t)Lh * sizeof(float),
+                                             data + ((size_t)f * W + xs) * H + ys, (size_t)H * sizeof(float), (size_t)(ye - ys) * sizeof(float),
+                                             (size_t)(xe - xs), hipMemcpyDeviceToDevice, sub->stream));
+                if (int rc = fftconv_plan_set_image(sub, ts->blk.p, FFTCONV_DEVICE)) return rc;
+            }
+        }
+        ts->have_image = true;
+        return 0;
+    }
     if (location == FFTCONV_HOST) ts->hblk.assign((size_t)Bh * Bw * F, 0.f);
     else if (int rc = ts->blk.ensure((size_t)Bh * Bw * F)) return rc;
     for (int b = 0; b < ts->nblk; b++) {
@@ -992,6 +1137,87 @@ int tiled_set_image(fftconv_plan* p, const float* data, int location) {
     return 0;
 }
 
+// Overlap-save: every block's run stores its rectangle of the maps from the output kernel (OutWindow) -- no block maps, no
+// summing pass, every element of the maps written once.  Kernels of equal size go through the block plan group by group
+// (run_group); host kernels, and device kernels that are not consecutive in memory, are packed on the device once per call.
+int tiled_convolve_save(fftconv_plan* p, int n, const float* const* kernels, const int* kh, const int* kw, int kernel_location,
+                        float* const* out, int out_location, float* out_packed) {
+    TiledState* ts = p->tiled;
+    fftconv_plan* sub = ts->sub;
+    const size_t big_map = ts->big_map();
+    const size_t budget = (size_t)6 << 30;
+    const int nc = out_packed ? n : (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / (big_map * sizeof(float))));
+    if (!out_packed)
+        if (int rc = ts->big.ensure(big_map * nc)) return rc;
+    FC_VERBOSE(p, "N Kernel: %d (block-wise, overlap-save: %d blocks, %d kernels per chunk)", n, ts->nblk, nc);
+    struct Group { int first, count; const float* dk; };
+    for (int k0 = 0; k0 < n; k0 += nc) {
+        const int nk = std::min(nc, n - k0);
+        float* big = out_packed ? out_packed + (size_t)k0 * big_map : ts->big.p;
+        // groups of consecutive kernels of equal size, each packed on the device
+        std::vector<Group> groups;
+        size_t stage_total = 0;
+        for (int j = 0; j < nk;) {
+            int e = j + 1;
+            while (e < nk && kh[k0 + e] == kh[k0 + j] && kw[k0 + e] == kw[k0 + j]) e++;
+            const size_t per = (size_t)ts->F * kh[k0 + j] * kw[k0 + j];
+            bool packed = kernel_location == FFTCONV_DEVICE;
+            for (int i = j + 1; i < e && packed; i++) packed = kernels[k0 + i] == kernels[k0 + i - 1] + per;
+            groups.push_back(Group{j, e - j, packed ? kernels[k0 + j] : nullptr});
+            if (!packed) stage_total += per * (size_t)(e - j);
+            j = e;
+        }
+        if (stage_total) {
+            if (int rc = ts->kstage.ensure(stage_total)) return rc;
+            size_t off = 0;
+            for (Group& gr : groups) {
+                if (gr.dk) continue;
+                const size_t per = (size_t)ts->F * kh[k0 + gr.first] * kw[k0 + gr.first];
+                gr.dk = ts->kstage.p + off;
+                for (int i = 0; i < gr.count; i++, off += per)
+                    HIP_TRY(hipMemcpyAsync(ts->kstage.p + off, kernels[k0 + gr.first + i], per * sizeof(float),
+                                           kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice
+                                           : kernel_location == FFTCONV_AUTO ? hipMemcpyDefault : hipMemcpyDeviceToDevice, sub->stream));
+            }
+        }
+        for (int b = 0; b < ts->nblk; b++) {
+            const int y0 = (b % ts->nbh) * ts->Bh, x0 = (b / ts->nbh) * ts->Bw;       // the block's rectangle of the maps starts here
+            if (int rc = fftconv_plan_use_spectrum_buffer(sub, ts->spec_base() + (size_t)b * ts->spec_elems, ts->spec_elems * sizeof(c32))) return rc;
+            if (int rc = fftconv_plan_mark_spectrum_valid(sub)) return rc;
+            OutWindow win;
+            win.map_stride = big_map; win.pitch = ts->FH;
+            win.h_lo = ts->Sh; win.h_hi = ts->Sh + std::min(ts->Bh, ts->FH - y0);
+            win.w_first = ts->Sw; win.ncols = std::min(ts->Bw, ts->FW - x0);
+            int rc = 0;
+            for (const Group& gr : groups) {
+                // (row h of column w of the block's result belongs at row y0 + h - Sh of column x0 + w - Sw of the map)
+                win.base = big + (size_t)gr.first * big_map + ((ptrdiff_t)(x0 - ts->Sw) * ts->FH + (y0 - ts->Sh));
+                sub->win = &win;
+                Sink sink;
+                sink.packed = win.base;     // unused: the window decides where the maps go
+                // one group that fits one chunk of column spectra: block 0 left the kernels' column spectra in the block plan
+                // (every block runs the same transform), the other blocks reuse them
+                if (b > 0 && groups.size() == 1 && gr.count <= batch_sizes(sub, gr.count, kw[k0 + gr.first]).nbA && !sub->deferred.on) {
+                    sub->prepared.dk = gr.dk; sub->prepared.n = gr.count; sub->prepared.kh = kh[k0 + gr.first]; sub->prepared.kw = kw[k0 + gr.first];
+                    sub->prepared.stream = sub->stream;
+                }
+                rc = run_group(sub, gr.count, gr.dk, kh[k0 + gr.first], kw[k0 + gr.first], sink);
+                sub->win = nullptr;
+                if (rc) return rc;
+            }
+        }
+        if (!out_packed) {
+            for (int j = 0; j < nk; j++)
+                HIP_TRY(hipMemcpyAsync(out[k0 + j], big + (size_t)j * big_map, big_map * sizeof(float),
+                                       out_location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sub->stream));
+            if (out_location == FFTCONV_HOST || k0 + nc < n) HIP_TRY(hipStreamSynchronize(sub->stream));   // `big` is reused by the next chunk
+        }
+        if (stage_total && k0 + nc < n) HIP_TRY(hipStreamSynchronize(sub->stream));                       // ... and so is the kernel staging
+    }
+    FC_VERBOSE(p, "FFT done");
+    return 0;
+}
+
 // n kernels (pointers, any location) -> n full maps.  out_packed != nullptr: device memory, maps consecutive (the block
 // results are summed straight into it); else one pointer per map in `out` (host or device memory).
 int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const int* kh, const int* kw, int kernel_location,
@@ -1008,6 +1234,7 @@ int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const in
         if (kh[k] > ts->mkh || kw[k] > ts->mkw)
             return fail(FFTCONV_ERR_KERNEL_EXCEEDS_MAX, "kernel %dx%d exceeds MAX_KERNEL %dx%d (block-wise path)", kh[k], kw[k], ts->mkh, ts->mkw);
     }
+    if (ts->save) return tiled_convolve_save(p, n, kernels, kh, kw, kernel_location, out, out_location, out_packed);
     const size_t big_map = ts->big_map(), blk_map = sub->g.map_elems();
     const size_t budget = (size_t)6 << 30;
     const int nc = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / ((big_map + blk_map) * sizeof(float))));
@@ -1240,6 +1467,14 @@ int fftconv_plan_is_live(const fftconv_plan* plan) {
 
 int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feature_dim, int max_kernel_h,
                            int max_kernel_w, int gpu_id, void* hip_stream, const fftconv_plan_options* options) {
+    return plan_create_internal(plan, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, hip_stream, options, false);
+}
+
+}  // extern "C"
+
+// cyclic: the block plan of an overlap-save block-wise plan (PlanTuning::cyclic) -- never block-wise itself
+int plan_create_internal(fftconv_plan** plan, int data_h, int data_w, int feature_dim, int max_kernel_h, int max_kernel_w, int gpu_id,
+                         void* hip_stream, const fftconv_plan_options* options, bool cyclic) {
     if (!plan) return fail(FFTCONV_ERR_INVALID_ARG, "plan is NULL");
     *plan = nullptr;
     if (data_h < 1 || data_w < 1 || feature_dim < 1) return fail(FFTCONV_ERR_INVALID_ARG, "Invalid data input");
@@ -1254,14 +1489,24 @@ int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feat
         delete p;
         return fail(FFTCONV_ERR_INVALID_ARG, "fftconv_plan_options.struct_size is not set");
     }
-    const PlanTuning tune = tuning_from(options);
+    PlanTuning tune = tuning_from(options);
+    tune.cyclic = cyclic;
+    if (cyclic) { tune.exact_window = false; tune.max_transform = 0; }
     p->opt_verbose = options_verbose(options) ? 1 : 0;
     p->gpu_id = gpu_id;
     p->stream = reinterpret_cast<hipStream_t>(hip_stream);
-    if (!make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, tune)) {
-        // too large for one LDS-resident pass (or beyond max_transform): a block-wise plan, unless the caller opted out
+    const bool may_block = !cyclic && !options_no_blockwise(options) && !tune.exact_window;
+    bool single_pass = make_geometry(p->g, p->t, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, tune);
+    // large single-pass sizes run on the slower long-transform kernels: blocks of a mid-sized transform (overlap-save, the
+    // output kernel storing each block's rectangle of the maps directly) are faster where the cost model says so
+    if (single_pass && may_block && blocks_preferred(p->g, options)) single_pass = false;
+    if (!single_pass) {
+        // too large for one LDS-resident pass (or beyond max_transform), or faster in blocks: a block-wise plan, unless the caller opted out
         int rc = FFTCONV_ERR_UNSUPPORTED_SIZE;
-        if (options_no_blockwise(options) || tune.exact_window)
+        if (cyclic)
+            (void)fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "no specialised kernels for a %dx%d block transform with kernels up to %dx%d", data_h, data_w,
+                       max_kernel_h, max_kernel_w);
+        else if (options_no_blockwise(options) || tune.exact_window)
             (void)fail(FFTCONV_ERR_UNSUPPORTED_SIZE, "sizes %dx%dx%d with kernels up to %dx%d do not fit the single-pass LDS transform%s", data_h,
                        data_w, feature_dim, max_kernel_h, max_kernel_w, tune.max_transform > 0 ? " within max_transform" : "");
         else
@@ -1342,6 +1587,8 @@ int fftconv_plan_create_ex(fftconv_plan** plan, int data_h, int data_w, int feat
     *plan = p;
     return 0;
 }
+
+extern "C" {
 
 int fftconv_plan_destroy(fftconv_plan* plan) {
     if (!plan) return 0;
@@ -1723,6 +1970,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
 int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!plan || !name || !value) return fail(FFTCONV_ERR_INVALID_ARG, "null argument");
     if (!strcmp(name, "blockwise")) { *value = plan->tiled ? plan->tiled->nblk : 0; return 0; }   // read-only: number of blocks (0 = one pass)
+    if (!strcmp(name, "overlap_save")) { *value = plan->tiled && plan->tiled->save ? 1 : 0; return 0; }   // read-only: blocks stored by the output kernel (1) or summed (0)
     if (plan->tiled) return fftconv_plan_get_option(plan->tiled->sub, name, value);
     if (!strcmp(name, "batch_maps")) { *value = plan->opt_batch_maps; return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { *value = plan->opt_kernel_chunk_mb; return 0; }

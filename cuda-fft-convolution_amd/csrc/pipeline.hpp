@@ -30,6 +30,10 @@ struct PlanTuning {
     // transform lengths must equal the ceil16 window (the reference's circular modulus; needed to
     // exchange spectra in the reference's order); unsupported windows then fail
     bool exact_window = false;
+    // the block plan of an overlap-save block-wise plan (fftconv_api.cpp): H x W IS the transform (a block of the image with
+    // its history rows / columns), the result is the circular convolution modulo H x W, and the caller stores the part of
+    // it that is not wrapped.  Needs both specialised hot kernels and the tiled intermediate.
+    bool cyclic = false;
 };
 
 struct Geometry {
@@ -123,13 +127,14 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     // row, F times the traffic of F = 1; the XCD-aware order with the kernel index fastest lets the
     // workgroups of one row take it from their XCD's L2 (cfg3 with F = 4: 92 -> 79 us per map)
     g.rows_wg_order = F > 1 ? 2 : 0;
-    g.fft_h = fft_size16(H + max_kh - 1);
-    g.fft_w = fft_size16(W + max_kw - 1);
+    g.fft_h = tune.cyclic ? H : fft_size16(H + max_kh - 1);
+    g.fft_w = tune.cyclic ? W : fft_size16(W + max_kw - 1);
+    if (tune.cyclic && (!allow_fast || (H & 1) || max_kh > H || max_kw > W)) return false;
     LengthPrefs prefs;   // the planner prefers lengths with specialised kernels (able to take max_kw)
     if (allow_fast) { prefs.fast_rows = &fast_rows_factor; prefs.fast_cols = &fast_cols_factor; prefs.max_kw = max_kw; }
     g.Lh = choose_length(H + max_kh - 1, true, g.fft_h, prefs);
     g.Lw = choose_length(W + max_kw - 1, false, g.fft_w, prefs);
-    if (tune.exact_window) {
+    if (tune.exact_window || tune.cyclic) {
         if (!length_supported(g.fft_h / 2) || !length_supported(g.fft_w)) return false;
         g.Lh = g.fft_h;
         g.Lw = g.fft_w;
@@ -160,6 +165,7 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     // the plan whose digit-reversed order the spectrum rows are produced in
     Plan1D producer = g.fast_fwd ? make_plan1d_seq(g.M, {g.fast_cols.R1, g.fast_cols.R2, g.fast_cols.R3}) : t.pm;
     if (g.fast_cols.ok) t.fcl = make_fast_cols_tables(g.fast_cols, producer, g.y_pitch);
+    if (tune.cyclic && !g.y_tiled()) return false;
     t.nat_row_of.assign(g.rows, g.M);                       // bin M (Nyquist) lives in the extra row M
     for (int k = 0; k < g.M; k++) t.nat_row_of[k] = producer.pos[k];
     t.nat_col_of.assign(g.Lw, 0);
@@ -262,6 +268,7 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     FastColsArgs a{};
     a.Y = Y; a.y_kernel_stride = g.y_elems_per_kernel(); a.y_pitch = g.y_pitch;
     a.out = out; a.out_kernel_stride = out_kernel_stride; a.fft_h = g.fft_h; a.fft_w = g.fft_w;
+    a.h_lo = 0; a.w_first = 0; a.out_pitch = g.fft_h;
     a.tiles_per_kernel = g.fft_w / g.fast_cols.T; a.ntiles = a.tiles_per_kernel * nk;
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
     a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift;

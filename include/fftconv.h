@@ -90,9 +90,9 @@ int fftconv_device_count(int *count);
  *   fft_h, fft_w                        out, nullable: the window size
  * Synchronous: results are complete on return.  The plan (tables, device scratch) goes back into the
  * plan cache below instead of being torn down; fftconv_cache_clear() releases it.
- * Images whose padded size exceeds what one plan transforms in a single pass (the plan API
- * reports FFTCONV_ERR_UNSUPPORTED_SIZE) are convolved block-wise here: overlap-add over
- * ordinary plans, the block results summed on the device into the full FFT_H x FFT_W maps
+ * Images whose padded size exceeds what one plan transforms in a single pass, and large images that
+ * run faster that way, are convolved block-wise (fftconv_plan_options.blockwise): blocks of a
+ * shorter transform, each block's rectangle of the FFT_H x FFT_W maps stored by the output kernel
  * (kernels larger than MAX_KERNEL are rejected on that path).
  * ------------------------------------------------------------------------------------------ */
 int fftconv_convolution_fft(const float *data, int data_h, int data_w, int feature_dim,
@@ -192,20 +192,27 @@ typedef struct fftconv_plan_options {
     int rows_group;     /* maps one workgroup of the spectral-row kernel walks with its image-spectrum row in
                          *    registers (F = 1): 0 (default) chosen per launch, 1 one map per workgroup, n > 1 fixed */
     int max_transform;  /* > 0: largest transform length a plan may use; beyond it the plan is block-wise
-                         *    (overlap-add) with blocks of at most this size (see `blockwise`) */
+                         *    with block transforms of at most this size (see `blockwise`) */
     int exact_window;   /* 1: the transform lengths must be the ceil16 window FFT_H x FFT_W itself (the
                          *    reference's circular modulus, plan_info.exact_window = 1) -- what
                          *    fftconv_plan_export_spectrum / _import_spectrum need; creation fails with
                          *    FFTCONV_ERR_UNSUPPORTED_SIZE when the window has a prime factor above 17 */
-    int blockwise;      /* Padded sizes beyond one LDS-resident transform pass (about 20 000 samples along w) or beyond
-                         *    max_transform: 0 (default) the plan convolves block-wise -- overlap-add over an ordinary block
-                         *    plan, block spectra kept per image; every plan entry point works (two-step, packed
-                         *    device-resident, multi-device), except the spectrum exchange in the reference's order and
-                         *    "output_region"; kernels larger than MAX_KERNEL are rejected there.  1: creation fails
-                         *    with FFTCONV_ERR_UNSUPPORTED_SIZE instead.  (Appended in 0.2: a struct_size without this
-                         *    field is accepted and means 0.)  fftconv_plan_get_option "blockwise" reads the number of
-                         *    blocks of a plan (0 = single pass).  The reference plans cuFFT for any size:
-                         *    src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98. */
+    int blockwise;      /* 0 (default): the plan convolves block-wise where that is needed or faster -- padded sizes beyond one
+                         *    LDS-resident transform pass (about 20 000 samples along w) or beyond max_transform, and sizes whose
+                         *    one-pass transform would run on the slower long-transform kernels (from about 4900 x 4900 with
+                         *    63 x 63 kernels; the planner weighs measured costs per length).  Blocks are overlap-save over a
+                         *    block plan whose transform has specialised kernels: every block is a piece of the image with
+                         *    MAX_KERNEL - 1 history rows / columns, convolved circularly, and the output kernel stores the part
+                         *    that is not wrapped straight into the block's rectangle of the maps (nothing is summed, every
+                         *    element is written once); where the block transform has no specialised kernels (kernel_path = 1,
+                         *    very wide kernels) blocks are zero-padded and summed (overlap-add).  Block spectra are kept per
+                         *    image; every plan entry point works (two-step, packed device-resident, multi-device), except the
+                         *    spectrum exchange in the reference's order and "output_region"; kernels larger than MAX_KERNEL
+                         *    are rejected there.  1: never block-wise -- one pass, or FFTCONV_ERR_UNSUPPORTED_SIZE.  (Appended
+                         *    in 0.2: a struct_size without this field is accepted and means 0.)  fftconv_plan_get_option
+                         *    "blockwise" reads the number of blocks of a plan (0 = single pass), "overlap_save" whether they are
+                         *    stored (1) or summed (0); plan_info.transform_h / _w are the block transform then.  The reference
+                         *    plans cuFFT for any size: src/cudaFFTData.cu:72-103, src/cudaConvFFTData.cu:92-98. */
     int verbose;        /* 1: the plan starts with option "verbose" on (the reference's compile-time `debug`,
                          *    src/cudaConvolutionFFT.cu:9), and a one-shot call prints where its time went
                          *    (fftconv_call_timing).  (Appended in 0.3; a struct_size without it means 0.) */
@@ -325,7 +332,7 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             conjugate-product variant commented out, src/cudaConvFFTData.cuh:42-45,63). */
 int fftconv_plan_set_option(fftconv_plan *plan, const char *name, long value);
 /* Current value of an option, plus read-only ones: "tuned_candidates" (allocations tried by the last placement tuning)
- * and "tuned_best" (index of the one kept), "blockwise" (blocks of a block-wise plan, 0 = one pass),
+ * and "tuned_best" (index of the one kept), "blockwise" (blocks of a block-wise plan, 0 = one pass), "overlap_save" (1: the blocks are stored by the output kernel),
  * "rows_slots_per_cu" (workgroups of the multi-map row kernel a CU holds at once: what the walk length is chosen for),
  * "specialised_kernels" (bit 0: the spectral-row pass runs on a specialised kernel, bit 1: the column passes do; 3 = no
  * generic kernel runs for this plan). */

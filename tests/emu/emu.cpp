@@ -17,6 +17,8 @@ using namespace emu;
 
 namespace {
 PlanTuning g_tune;   // path mode / rows group of the emulated plans (pipeline.hpp PlanTuning)
+// the output window of a block of an overlap-save block-wise plan (fftconv_api.cpp: OutWindow), applied to the output kernel
+struct { bool on = false; int h_lo = 0, h_hi = 0, w_first = 0, ncols = 0, pitch = 0; } g_win;
 }  // namespace
 
 extern "C" {
@@ -115,9 +117,14 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
             d.fc_pairs = t.fcl.pairs.data();
             d.fc_rowoff = t.fcl.rowoff.data();
             FastColsArgs fa = fast_cols_args(g, d, Y.data(), out[k], 0, 1);
+            if (g_win.on) {
+                fa.h_lo = g_win.h_lo; fa.fft_h = g_win.h_hi; fa.w_first = g_win.w_first; fa.out_pitch = g_win.pitch;
+                fa.tiles_per_kernel = g_win.ncols / g.fast_cols.T; fa.ntiles = fa.tiles_per_kernel;
+            }
             EmuFastCols run{fa, lds.data(), 3};   // 3 persistent workgroups share the tiles
             if (!run_fast_cols(g.M, g.fast_cols.T, run)) return -6;
         } else {
+            if (g_win.on) return -7;
             ColsC2RArgs ca = cols_c2r_args(g, t, d, Y.data(), out[k], 0);
             for (int tile = 0; tile < tiles_for(g.fft_w, g.T_cols); tile++) cols_c2r_body(ctx, lds.data(), ca, tile, 0);
         }
@@ -164,6 +171,13 @@ void emu_set_tuning(int path_mode, int rows_group) { g_tune.path_mode = path_mod
 // 1: the emulated plans transform the ceil16 window itself (fftconv_plan_options.exact_window)
 void emu_set_exact_window(int on) { g_tune.exact_window = on != 0; }
 void emu_allow_fast(int mode) { g_tune.path_mode = mode; }
+// 1: the emulated plans are block plans of an overlap-save block-wise plan: H x W is the transform, the result circular
+void emu_set_cyclic(int on) { g_tune.cyclic = on != 0; }
+// the window the output kernel stores (on = 0: the whole window at out[k]): rows [h_lo, h_hi) of columns [w_first, w_first + ncols)
+// of the result, row h of column w at out[k] + w * pitch + h
+void emu_set_out_window(int on, int h_lo, int h_hi, int w_first, int ncols, int pitch) {
+    g_win.on = on != 0; g_win.h_lo = h_lo; g_win.h_hi = h_hi; g_win.w_first = w_first; g_win.ncols = ncols; g_win.pitch = pitch;
+}
 // 1 if a plan of these sizes would use the fast spectral-row kernel
 int emu_uses_fast_rows(int H, int W, int F, int max_kh, int max_kw) {
     Geometry g;

@@ -187,6 +187,69 @@ def test_emulated_native_window_kernels(emu, oracle, tuned, shape, variant):
         emu.emu_set_exact_window(0)
 
 
+# Overlap-save blocks (block-wise plans whose block transform has specialised kernels, fftconv_api.cpp: tiled_convolve_save): the
+# block plan is CYCLIC over Lh x Lw samples (a block of the image with S history rows / columns in front), and the output kernel
+# stores the part of each block's circular result that is not wrapped straight into the block's rectangle of the full map.  The
+# emulator runs the kernel bodies with the same arguments; the block loop below restates the host logic of the product.
+def emu_overlap_save(emu, data, mkh, mkw, kernels, Lh, Lw):
+    d, ks, n, kp, kh, kw = util.Oracle._prep(data, kernels)
+    H, W, F = d.shape
+    FH, FW = util.ceil16(H + mkh - 1), util.ceil16(W + mkw - 1)
+
+    def dim(window, mk, L):      # blocks, history
+        if L >= window:
+            return 1, 0
+        S = (max(0, mk - 1) + 15) // 16 * 16
+        return -(-window // (L - S)), S
+    (nbh, Sh), (nbw, Sw) = dim(FH, mkh, Lh), dim(FW, mkw, Lw)
+    Bh, Bw = Lh - Sh, Lw - Sw
+    outs = [np.full((FH, FW), 7e7, dtype=np.float32, order="F") for _ in range(n)]
+    emu.emu_set_cyclic(1)
+    try:
+        for bx in range(nbw):
+            for by in range(nbh):
+                y0, x0 = by * Bh - Sh, bx * Bw - Sw
+                blk = np.zeros((Lh, Lw, F), dtype=np.float32, order="F")
+                ys, ye, xs, xe = max(0, y0), min(H, y0 + Lh), max(0, x0), min(W, x0 + Lw)
+                if ye > ys and xe > xs:
+                    blk[ys - y0:ye - y0, xs - x0:xe - x0, :] = d[ys:ye, xs:xe, :]
+                emu.emu_set_out_window(1, Sh, Sh + min(Bh, FH - by * Bh), Sw, min(Bw, FW - bx * Bw), FH)
+                op = (ctypes.c_void_p * n)(*[o.ctypes.data + 4 * (x0 * FH + y0) for o in outs])
+                rc = emu.emu_conv_fft(ctypes.c_void_p(blk.ctypes.data), Lh, Lw, F, mkh, mkw, n, kp, kh, kw, op, None, None)
+                if rc:
+                    return rc, outs, (nbh, nbw)
+    finally:
+        emu.emu_set_cyclic(0)
+        emu.emu_set_out_window(0, 0, 0, 0, 0, 0)
+    return 0, outs, (nbh, nbw)
+
+
+@pytest.mark.parametrize("case", [
+    ((700, 500, 2, 9, 13, 3), 288, 288, (3, 2)),      # blocks in both dimensions, ragged edge blocks, ragged kernels
+    ((600, 250, 1, 31, 17, 2), 288, 288, (3, 1)),     # one block covers w (no history there, zero padding instead)
+    ((250, 1200, 1, 16, 33, 2), 288, 576, (1, 3)),    # ... covers h; 576-point rows
+    ((1100, 270, 3, 1, 1, 1), 576, 288, (2, 1)),      # 1 x 1 kernels: no history at all
+])
+def test_emulated_overlap_save_blocks(emu, oracle, case):
+    shape, Lh, Lw, blocks = case
+    H, W, F, kh, kw, n = shape
+    data, ks = make_inputs(shape, 61)
+    rc, got, nb = emu_overlap_save(emu, data, kh, kw, ks, Lh, Lw)
+    assert rc == 0 and nb == blocks
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5          # every element written (the 7e7 fill would show) and equal to the one-pass result
+
+
+def test_cyclic_plans_need_both_specialised_kernels(emu):
+    emu.emu_set_cyclic(1)
+    try:
+        assert emu.emu_uses_fast_rows(288, 576, 1, 9, 9) == 3
+        assert emu.emu_uses_fast_rows(320, 576, 1, 9, 9) == -1        # no output kernel for 160 points: such a block plan is refused
+        assert emu.emu_uses_fast_rows(288, 600, 1, 9, 9) == -1
+    finally:
+        emu.emu_set_cyclic(0)
+
+
 def test_fast_row_kernel_rejects_too_wide_kernels(emu):
     # the fast row kernel takes kernels up to its stage-1 sub-length (528 for L = 4224, 704 for L = 7040, the widest); plans for
     # wider MAX_KERNEL_W fall back to the generic kernel at plan time

@@ -706,6 +706,100 @@ def test_blockwise_plan_api_every_entry(fc, oracle, shape):
             assert util.rel_err(g, r) < TIGHT
 
 
+# ---- block-wise, overlap-save: blocks whose transform has specialised kernels; the output kernel stores each block's
+# rectangle of the maps (no block maps, no summing pass).  max_transform = 288 / 576 makes small problems take it; large
+# single-pass sizes take it by themselves where the planner's cost model says blocks are faster. -------------------------
+
+@pytest.mark.parametrize("case", [
+    ((700, 500, 2, 9, 13, 5), 288, 6),       # 3 x 2 blocks of 288 x 288, ragged edge blocks, ragged kernels, F = 2
+    ((1000, 300, 1, 31, 17, 3), 576, 2),     # blocks along h only (one 576-point block covers w)
+    ((300, 1500, 3, 16, 16, 4), 576, 3),     # ... along w only
+    ((560, 1130, 1, 1, 1, 2), 576, 2),       # 1 x 1 kernels: blocks without history
+])
+def test_overlap_save_blocks_every_entry(fc, oracle, case):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    shape, mt, nblk = case
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape) + 7)
+    opts = {"max_transform": mt}
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    data2 = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    if n > 2:
+        ks[1] = rng.standard_normal((max(1, kh - 2), max(1, kw - 1), F)).astype(np.float32)      # ragged cell: three groups of kernels
+    ref = oracle.conv_fft(data, kh, kw, ks)
+    fh, fw = util.ceil16(H + kh - 1), util.ceil16(W + kw - 1)
+    for g, r in zip(fc.cudaConvolutionFFT(data, kh, kw, ks, options=opts), ref):      # one-shot entry
+        assert g.shape == r.shape and util.rel_err(g, r) < TIGHT
+    with fc.Plan(H, W, F, kh, kw, options=opts) as p:
+        assert p.get_option("blockwise") >= nblk and p.get_option("overlap_save") == 1
+        assert (p.info.fft_h, p.info.fft_w) == (fh, fw) and p.info.map_bytes == fh * fw * 4
+        p.set_image(data)
+        for rep in range(2):
+            for g, r in zip(p.convolve(ks), ref):
+                assert g.shape == (fh, fw) and util.rel_err(g, r) < TIGHT
+        # device-resident image, packed device-resident kernels and maps (what bench.py uses); NaN-filled maps: every element is written
+        same = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+        ref2 = oracle.conv_fft(data2, kh, kw, same)
+        img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(data2, (2, 1, 0)))).to(dev)
+        k_d = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in same]))).to(dev)
+        out = torch.full((n, fw, fh), float("nan"), dtype=torch.float32, device=dev)
+        p.set_image_device(img_d.data_ptr())
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+        for j, r in enumerate(ref2):
+            assert util.rel_err(out[j].cpu().numpy().T, r) < TIGHT
+        p.set_option("flip_kernels", 1)                                   # correlation through the blocks
+        p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+        p.set_option("flip_kernels", 0)
+        for j, r in enumerate(oracle.conv_fft(data2, kh, kw, [k[::-1, ::-1, :].copy() for k in same])):
+            assert util.rel_err(out[j].cpu().numpy().T, r) < TIGHT
+        with pytest.raises(fc.FFTConvError) as ei:          # a kernel beyond MAX_KERNEL would wrap into the stored part: rejected
+            p.convolve([np.zeros((kh + 1, kw, F), np.float32)])
+        assert ei.value.status == -4
+    with fc.Plan(H, W, F, kh, kw, options=dict(opts, kernel_path=1)) as p:     # generic kernels only: blocks are summed (overlap-add)
+        assert p.get_option("blockwise") > 1 and p.get_option("overlap_save") == 0
+        p.set_image(data)
+        for g, r in zip(p.convolve(ks), ref):
+            assert util.rel_err(g, r) < TIGHT
+    with fc.MultiPlan(H, W, F, kh, kw, [0, 0], options=opts) as mp:      # the spectrum copied between plans is every block's
+        mp.set_image(data)
+        for g, r in zip(mp.convolve(ks), ref):
+            assert util.rel_err(g, r) < TIGHT
+
+
+def test_large_sizes_run_in_blocks_where_the_cost_model_says_so(fc, oracle):
+    """4900 x 4900 with 63 x 63 kernels: one pass would transform 5120 x 5120 (4-column output kernel); the default plan runs
+    2 x 2 blocks of 2560 x 2560 instead.  Same maps as the one-pass plan (blockwise = 1) and as the oracle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H = W = 4900
+    K, n = 63, 2
+    rng = np.random.default_rng(4900)
+    data = rng.random((H, W, 1), dtype=np.float32)
+    ks = [rng.random((K, K, 1), dtype=np.float32) for _ in range(n)]
+    img_d = torch.from_numpy(np.ascontiguousarray(np.transpose(data, (2, 1, 0)))).to(dev)
+    k_d = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in ks]))).to(dev)
+    outs = []
+    for opts in (None, {"blockwise": 1}):
+        with fc.Plan(H, W, 1, K, K, options=opts) as p:
+            i = p.info
+            assert (i.fft_h, i.fft_w) == (4976, 4976)
+            assert (p.get_option("blockwise") > 1) == (opts is None) and p.get_option("overlap_save") == (1 if opts is None else 0)
+            assert (i.transform_h <= 4608) == (opts is None)
+            out = torch.full((n, i.fft_w, i.fft_h), float("nan"), dtype=torch.float32, device=dev)
+            p.set_image_device(img_d.data_ptr())
+            p.convolve_packed_device(n, k_d.data_ptr(), K, K, out.data_ptr())
+            p.synchronize()
+            outs.append(out)
+    assert bool(torch.isfinite(outs[0]).all())
+    assert float((outs[0] - outs[1]).abs().max() / outs[1].abs().max()) < 2e-6
+    ref = oracle.conv_fft(data, K, K, ks[:1])[0]
+    assert util.rel_err(outs[0][0].cpu().numpy().T, ref) < TIGHT
+
+
 # ---- output_region: full / same / valid parts of the padded window ---------------------------------
 
 @pytest.mark.parametrize("shape", [(64, 8, 5, 10, 4, 3), (300, 260, 1, 31, 17, 5), (1024, 1024, 1, 63, 63, 2)])

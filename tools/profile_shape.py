@@ -9,6 +9,7 @@ H, W, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 F = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 opts = {"exact_window": 1} if os.environ.get("EXACT") else None
+if os.environ.get("ONE_PASS"): opts = dict(opts or {}, blockwise=1)      # never block-wise (A/B of the overlap-save blocks)
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(1)
 img = torch.from_numpy(rng.random((F, W, H), dtype=np.float32)).to(dev)
@@ -28,6 +29,6 @@ with fc.Plan(H, W, F, K, K, options=opts) as p:
     for _ in range(5): step()
     torch.cuda.synchronize()
     pr = p.profile(reset=True)
-    print("%dx%d K=%d F=%d n=%d window %dx%d transform %dx%d spec %d: %.1f us/step  %.1f Gpx/s | " % (H, W, K, F, n, i.fft_h, i.fft_w, i.transform_h, i.transform_w,
-          p.get_option("specialised_kernels"), dt * 1e6, n * i.fft_h * i.fft_w / dt / 1e9) +
+    print("%dx%d K=%d F=%d n=%d window %dx%d transform %dx%d%s spec %d: %.1f us/step  %.1f Gpx/s | " % (H, W, K, F, n, i.fft_h, i.fft_w, i.transform_h, i.transform_w,
+          (" x%d blocks" % p.get_option("blockwise")) if p.get_option("blockwise") else "", p.get_option("specialised_kernels"), dt * 1e6, n * i.fft_h * i.fft_w / dt / 1e9) +
           "  ".join("%s %.1f us x%d" % (k, v["ms"] / max(1, v["launches"]) * 1e3, v["launches"] // 5) for k, v in pr.items()))
