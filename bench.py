@@ -502,6 +502,13 @@ def main():
         idents = [None] * world
         dist.all_gather_object(idents, ident)
     distinct_devices = len(set((i["host"], i["pci_bus_id"] or i["uuid"] or i["device_index"]) for i in idents))
+    identity_source = "pci_bus_id"
+    if world > 1 and distinct_devices != world and not args.share_gpu:
+        # a host that reports the same (or no) PCI address for every device (virtual functions, some containers): ranks on
+        # distinct device indices of one runtime are still distinct devices -- say which evidence the count rests on
+        by_index = len(set((i["host"], i["device_index"]) for i in idents))
+        if by_index == world:
+            distinct_devices, identity_source = by_index, "device_index (the PCI ids of the ranks are not distinct)"
     if world > 1 and distinct_devices != world and not args.share_gpu:
         raise SystemExit("bench.py: %d ranks on %d distinct devices (%s); --share-gpu is the one-GPU rehearsal"
                          % (world, distinct_devices, [(i["host"], i["pci_bus_id"]) for i in idents]))
@@ -891,6 +898,7 @@ def main():
             result["config"]["backend"] = backend + (" (all ranks on cuda:0: rehearsal)" if args.share_gpu else "")
             result["ranks"] = idents
             result["distinct_devices"] = distinct_devices
+            result["distinct_devices_by"] = identity_source
             result["per_rank"] = per_rank
             if streamed:
                 result["config"]["pinned_images_numa"] = numa

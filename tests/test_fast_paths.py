@@ -356,24 +356,29 @@ def test_gpu_multi_map_row_kernel_auto_group_many_maps(fftconv, oracle):
         assert util.rel_err(got[i], r) < 1e-5
 
 
-def _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, expect_transform, sample, exact_window=0):
-    """device-resident maps of the specialised path (default) against the generic kernels
-    (kernel_path 1) on the same inputs"""
+def _specialised_vs_generic(fftconv, H, W, kh, kw, n, data, ks, expect_transform, sample, exact_window=0, variants=None):
+    """device-resident maps of the specialised path (in one pass at the expected transform: option blockwise = 1 -- or each
+    option set of `variants` with its own expectation about the plan) against the generic kernels (kernel_path 1) on the
+    same inputs"""
     torch = pytest.importorskip("torch")
     kd = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(x, (2, 1, 0)) for x in ks]))).cuda()
-    maps = {}
-    for mode in (2, 0):
-        with fftconv.Plan(H, W, 1, kh, kw, options=dict(plan_options((mode, -1)), exact_window=exact_window)) as p:
-            if mode == 2:
-                assert expect_transform(p.info.transform_h, p.info.transform_w)
+    runs = [(0, {}, None)] + [(2, o, e) for o, e in (variants or [({"blockwise": 1}, lambda p: expect_transform(p.info.transform_h, p.info.transform_w))])]
+    generic = None
+    for mode, extra, expect in runs:
+        with fftconv.Plan(H, W, 1, kh, kw, options=dict(plan_options((mode, -1)), exact_window=exact_window, **extra)) as p:
+            if expect is not None:
+                assert expect(p), (extra, p.info.transform_h, p.info.transform_w, p.get_option("blockwise"))
             p.set_image(data)
             od = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device="cuda")
             p.convolve_packed_device(n, kd.data_ptr(), kh, kw, od.data_ptr())
             p.synchronize()
-            maps[mode] = [od[j].cpu().numpy() for j in sample]
+            maps = [od[j].cpu().numpy() for j in sample]
             del od
-    for a, b in zip(maps[2], maps[0]):
-        assert util.rel_err(a, b) < 1e-5
+        if mode == 0:
+            generic = maps
+        else:
+            for a, b in zip(maps, generic):
+                assert util.rel_err(a, b) < 1e-5, extra
 
 
 @pytest.mark.gpu
@@ -382,13 +387,18 @@ def test_gpu_big_square_walk_with_remainder(fftconv, size, k):
     """both dimensions on the 6144 / 8448 configurations (two row workgroups per CU, 4-column output
     tiles, cropped window at 6000), 17 kernels = one full walk of 16 + a remainder of 1.  The float64
     oracle needs minutes at this size, so the specialised path is compared with the generic kernels
-    (kernel_path 1, themselves pinned to the oracle at every smaller size) on the same inputs."""
+    (kernel_path 1, themselves pinned to the oracle at every smaller size) on the same inputs.
+    Twice: in one pass (option blockwise = 1: the long-transform kernels) and as the default plan, which from about
+    4900 x 4900 runs overlap-save blocks of a shorter transform where the planner's measured costs say so."""
     H = W = size
     n = 17
     rng = np.random.default_rng(size)
     data = rng.random((H, W, 1), dtype=np.float32)
     ks = [rng.random((k, k, 1), dtype=np.float32) for _ in range(n)]
-    _specialised_vs_generic(fftconv, H, W, k, k, n, data, ks, lambda lh, lw: lh == lw and lh in (6144, 8448), (0, 7, n - 1))
+    one_pass = lambda p: p.get_option("blockwise") == 0 and p.info.transform_h == p.info.transform_w and p.info.transform_h in (6144, 8448)
+    default = lambda p: (p.get_option("blockwise") == 0 and p.info.transform_h in (6144, 8448)) or \
+                        (p.get_option("blockwise") > 1 and p.get_option("overlap_save") == 1 and p.get_option("specialised_kernels") == 3)
+    _specialised_vs_generic(fftconv, H, W, k, k, n, data, ks, None, (0, 7, n - 1), variants=[({"blockwise": 1}, one_pass), ({}, default)])
 
 
 @pytest.mark.gpu
