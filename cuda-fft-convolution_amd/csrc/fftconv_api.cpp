@@ -126,6 +126,60 @@ struct DevBuf {
     size_t bytes() const { return cap * sizeof(T); }
 };
 
+// Pinned host staging of the small-call path (host arrays in / out of a few hundred KB: the sizes the reference's demo
+// calls with).  A copy between pageable memory and the device is a blocking runtime call of 10-25 us whatever its size,
+// and the reference's entry makes one per kernel and one per map (src/cudaConvolutionFFT.cu:148,231,286).  Here the
+// CPU copies the caller's small arrays into / out of pinned buffers of the plan: an image or a kernel set of at most
+// FC_PIN_INPLACE_BYTES is then read by the column kernels IN PLACE over PCIe (no copy command at all), a larger one
+// (up to FC_PIN_IMAGE_BYTES) crosses in one asynchronous copy, and the maps of a launch come back in ONE copy.
+// `busy` is recorded behind the last GPU work that reads the buffer; the next fill waits for it.
+constexpr size_t FC_PIN_INPLACE_BYTES = (size_t)512 << 10;
+constexpr size_t FC_PIN_IMAGE_BYTES = (size_t)1 << 20;
+constexpr size_t FC_PIN_OUT_BYTES = (size_t)8 << 20;
+constexpr size_t FC_PIN_ONE_MAP_BYTES = (size_t)64 << 10;
+struct PinBuf {
+    char* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t busy = nullptr;
+    bool in_use = false;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (int rc = wait()) return rc;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = (bytes + 65535) & ~(size_t)65535;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(FFTCONV_ERR_ALLOC, "hipHostMalloc of %zu bytes failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    int wait() {                      // until the GPU work that reads the buffer is over
+        if (!in_use) return 0;
+        in_use = false;
+        hipError_t e = hipEventSynchronize(busy);
+        if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e));
+        return 0;
+    }
+    int mark(hipStream_t s) {         // everything queued on s so far may read the buffer
+        if (!busy) {
+            hipError_t e = hipEventCreateWithFlags(&busy, hipEventDisableTiming);
+            if (e != hipSuccess) { busy = nullptr; return fail(FFTCONV_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
+        }
+        hipError_t e = hipEventRecord(busy, s);
+        if (e != hipSuccess) return fail(FFTCONV_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+        in_use = true;
+        return 0;
+    }
+    void release() {
+        if (in_use && busy) (void)hipEventSynchronize(busy);
+        in_use = false;
+        if (busy) (void)hipEventDestroy(busy);
+        busy = nullptr;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
 // Host-output streaming (the reference's blocking pageable cudaMemcpy of every
 // map, src/cudaConvolutionFFT.cu:284-286, and the async intent of
 // src/cudaConvFFTDataStreams.cu:368-369,429-430): finished maps leave the device while the next
@@ -363,6 +417,9 @@ struct fftconv_plan {
     size_t out_elems() const { return opt_region ? (size_t)out_h * out_w : g.map_elems(); }
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
+    PinBuf pin_img, pin_k, pin_out;   // pinned host staging of small host arrays (PinBuf above)
+    hipEvent_t pin_out_done[2] = {nullptr, nullptr};   // copy into each half of pin_out complete
+    long opt_host_pinned = 1;         // 0: small host arrays take the plain copies (A/B, tests)
     DevBuf<c32> fr_tw1, fr_tw2;
     DevBuf<int> fr_map;
     DevBuf<c32> fc_tw1, fc_tw2;
@@ -455,6 +512,8 @@ struct fftconv_plan {
         fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_pair_row_of.release();
         nat_row_of.release(); nat_col_of.release(); NS.release();
+        pin_img.release(); pin_k.release(); pin_out.release();
+        for (int h = 0; h < 2; h++) { if (pin_out_done[h]) (void)hipEventDestroy(pin_out_done[h]); pin_out_done[h] = nullptr; }
     }
 };
 
@@ -857,6 +916,35 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
                     if (int rc = ring_drain(p, sink, prev.first, prev.count, prev.buf, stage.p + (size_t)prev.buf * nbY * oe)) return rc;
                 prev.valid = true; prev.first = a0 + y0; prev.count = ny; prev.buf = buf;
                 batch++;
+            } else if (staged && sink.location == FFTCONV_HOST && p->opt_host_pinned && oe * sizeof(float) <= FC_PIN_OUT_BYTES / 2 &&
+                       (ny > 1 || oe * sizeof(float) <= FC_PIN_ONE_MAP_BYTES)) {
+                // small maps to host arrays: as many as fit the plan's pinned buffer come back in ONE copy and are handed
+                // out by the CPU (a copy into pageable memory is a blocking runtime call per map)
+                // (two halves: the copy of the next chunk runs while the CPU hands out the current one; a single map above
+                //  FC_PIN_ONE_MAP_BYTES takes the plain copy below: the CPU's pass over it costs more than the runtime's pinning --
+                //  one 324-KiB map: 77 against 60 us per convolve, four of them: 131 against 166, profiles/r04s_small_call_latency.txt)
+                const size_t mb = oe * sizeof(float);
+                const int per_copy = (int)std::min<size_t>((size_t)ny, (FC_PIN_OUT_BYTES / 2) / mb);
+                const int nchunks = (ny + per_copy - 1) / per_copy;
+                if (int rc = p->pin_out.ensure((size_t)per_copy * mb * (nchunks > 1 ? 2 : 1))) return rc;
+                for (int h = 0; h < 2; h++)
+                    if (!p->pin_out_done[h]) HIP_TRY(hipEventCreateWithFlags(&p->pin_out_done[h], hipEventDisableTiming));
+                auto copy_chunk = [&](int c) -> hipError_t {
+                    const int j0 = c * per_copy, nj = std::min(per_copy, ny - j0);
+                    hipError_t e = hipMemcpyAsync(p->pin_out.p + (size_t)(c & 1) * per_copy * mb, stage.p + (size_t)j0 * oe, (size_t)nj * mb,
+                                                  hipMemcpyDeviceToHost, p->stream);
+                    if (e == hipSuccess) e = hipEventRecord(p->pin_out_done[c & 1], p->stream);
+                    return e;
+                };
+                HIP_TRY(copy_chunk(0));
+                for (int c = 0; c < nchunks; c++) {
+                    if (c + 1 < nchunks) HIP_TRY(copy_chunk(c + 1));
+                    HIP_TRY(hipEventSynchronize(p->pin_out_done[c & 1]));
+                    const int j0 = c * per_copy, nj = std::min(per_copy, ny - j0);
+                    for (int j = 0; j < nj; j++)
+                        memcpy(sink.ptrs[a0 + y0 + j0 + j], p->pin_out.p + ((size_t)(c & 1) * per_copy + j) * mb, mb);
+                }
+                // (the staging buffer is free again: its last copy has been waited for)
             } else if (staged) {
                 for (int j = 0; j < ny; j++) {
                     float* dst = sink.ptrs[a0 + y0 + j];
@@ -1643,11 +1731,26 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
     if (int rc = use_device(p)) return rc;
     if (p->tiled) return tiled_set_image(p, data, location);
     const float* dimg = data;
+    bool image_pinned = false;      // the caller's array has been consumed by the CPU: no wait for the GPU at the end
     if (location == FFTCONV_HOST) {
         const size_t n = (size_t)g.H * g.W * g.F;
-        if (int rc = p->I.ensure(n)) return rc;
-        HIP_TRY(hipMemcpyAsync(p->I.p, data, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
-        dimg = p->I.p;
+        if (p->opt_host_pinned && n * sizeof(float) <= FC_PIN_IMAGE_BYTES) {
+            if (int rc = p->pin_img.ensure(n * sizeof(float))) return rc;
+            if (int rc = p->pin_img.wait()) return rc;
+            memcpy(p->pin_img.p, data, n * sizeof(float));
+            image_pinned = true;
+            if (n * sizeof(float) <= FC_PIN_INPLACE_BYTES) {
+                dimg = reinterpret_cast<const float*>(p->pin_img.p);      // the column pass reads it in place
+            } else {
+                if (int rc = p->I.ensure(n)) return rc;
+                HIP_TRY(hipMemcpyAsync(p->I.p, p->pin_img.p, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
+                dimg = p->I.p;
+            }
+        } else {
+            if (int rc = p->I.ensure(n)) return rc;
+            HIP_TRY(hipMemcpyAsync(p->I.p, data, n * sizeof(float), hipMemcpyHostToDevice, p->stream));
+            dimg = p->I.p;
+        }
     }
     FC_VERBOSE(p, "Using GPU : %d", p->gpu_id);                                                    // src/cudaConvolutionFFT.cu:87
     FC_VERBOSE(p, "Data size: h=%d, w=%d, f=%d", g.H, g.W, g.F);                                   // :100
@@ -1679,6 +1782,8 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         HIP_TRY(launch_cols_r2c(ia, tiles_for(g.W, g.T_cols), g.F, cols_threads(g), p->cols_lds(), p->stream));
     }
     if (int rc = p->prof_end()) return rc;
+    if (image_pinned)
+        if (int rc = p->pin_img.mark(p->stream)) return rc;      // the column pass (or the copy) is the last reader
     if (int rc = p->prof_begin(PK_IMAGE_ROWS, g.F)) return rc;
     if (g.fast_rows.ok) {
         HIP_TRY(launch_fast_rows_fwd(g.Lw, fast_rows_fwd_args(g, p->d, sgen), g.F * g.rows, p->stream));
@@ -1687,7 +1792,7 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         HIP_TRY(launch_rows_fwd(ra, g.F * g.rows, rows_threads(g), (size_t)g.Lw * sizeof(c32), p->stream));
     }
     if (int rc = p->prof_end()) return rc;
-    if (location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
+    if (location == FFTCONV_HOST && !image_pinned) HIP_TRY(hipStreamSynchronize(p->stream));
     p->have_image = true;
     return 0;
 }
@@ -1859,16 +1964,35 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
         while (k1 < n_kernel && kernel_h[k1] == kernel_h[k0] && kernel_w[k1] == kernel_w[k0]) k1++;
         const int n = k1 - k0, kh = kernel_h[k0], kw = kernel_w[k0];
         const size_t per = (size_t)g.F * kh * kw;
-        if (int rc = p->K.ensure(per * n)) return rc;
-        for (int j = 0; j < n; j++)
-            HIP_TRY(hipMemcpyAsync(p->K.p + per * j, kernels[k0 + j], per * sizeof(float),
-                                   kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice
-                                   : kernel_location == FFTCONV_AUTO ? hipMemcpyDefault : hipMemcpyDeviceToDevice,
-                                   p->stream));
+        const float* dk = nullptr;
+        const bool kernels_pinned = kernel_location == FFTCONV_HOST && p->opt_host_pinned && per * n * sizeof(float) <= FC_PIN_INPLACE_BYTES;
+        if (kernels_pinned) {
+            // a small set of host kernels: gathered by the CPU into the plan's pinned buffer and read there, in place, by
+            // the kernels' column pass (one pass over them) -- no copy command, against one blocking copy per kernel
+            if (int rc = p->pin_k.ensure(per * n * sizeof(float))) return rc;
+            if (int rc = p->pin_k.wait()) return rc;
+            for (int j = 0; j < n; j++) memcpy(p->pin_k.p + per * j * sizeof(float), kernels[k0 + j], per * sizeof(float));
+            dk = reinterpret_cast<const float*>(p->pin_k.p);
+        } else {
+            if (int rc = p->K.ensure(per * n)) return rc;
+            for (int j = 0; j < n; j++)
+                HIP_TRY(hipMemcpyAsync(p->K.p + per * j, kernels[k0 + j], per * sizeof(float),
+                                       kernel_location == FFTCONV_HOST ? hipMemcpyHostToDevice
+                                       : kernel_location == FFTCONV_AUTO ? hipMemcpyDefault : hipMemcpyDeviceToDevice,
+                                       p->stream));
+            dk = p->K.p;
+        }
         Sink sink;
         sink.ptrs = out + k0;
         sink.location = out_location;
-        if (int rc = run_group(p, n, p->K.p, kh, kw, sink)) return rc;
+        const int rcg = run_group(p, n, dk, kh, kw, sink);
+        if (kernels_pinned) {
+            const std::string keep = g_last_error;
+            const int rcm = p->pin_k.mark(p->stream);
+            if (rcg) g_last_error = keep;
+            else if (rcm) return rcm;
+        }
+        if (rcg) return rcg;
         k0 = k1;
     }
     if (out_location == FFTCONV_HOST) HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1949,6 +2073,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         return 0;
     }
     if (!strcmp(name, "flip_kernels")) { plan->opt_flip_kernels = value != 0; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
+    if (!strcmp(name, "host_pinned")) { plan->opt_host_pinned = value != 0; return 0; }
     if (!strcmp(name, "host_min_kb")) {
         if (value < 0 || value > (1 << 30)) return fail(FFTCONV_ERR_INVALID_ARG, "option '%s' out of range", name);
         plan->opt_host_min_kb = value;
@@ -1984,6 +2109,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "rows_slots_per_cu")) { *value = plan->g.rows_slots_per_cu; return 0; }   // read-only: resident row workgroups per CU
     if (!strcmp(name, "host_stream")) { *value = plan->opt_host_stream; return 0; }
     if (!strcmp(name, "host_min_kb")) { *value = plan->opt_host_min_kb; return 0; }
+    if (!strcmp(name, "host_pinned")) { *value = plan->opt_host_pinned; return 0; }
     if (!strcmp(name, "output_region")) { *value = plan->opt_region; return 0; }
     if (!strcmp(name, "flip_kernels")) { *value = plan->opt_flip_kernels; return 0; }
     if (!strcmp(name, "profile")) { *value = plan->profile ? 1 : 0; return 0; }

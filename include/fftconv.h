@@ -314,6 +314,13 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *          "host_threads", "host_chunk_kb", "host_slots" (shape of that machinery, 0 = auto),
  *          "host_min_kb" (maps smaller than this many KiB leave by blocking copies whatever "host_stream"
  *             says; default 1024: the copy threads buy small maps nothing),
+ *          "host_pinned" (1, default: small HOST arrays go through pinned staging buffers of the plan -- an image of at most
+ *             1 MiB and a kernel group of at most 512 KiB are copied by the CPU and read by the GPU from there (at most
+ *             512 KiB: in place, no copy command), maps of at most 4 MiB that leave by blocking copies come back several
+ *             per copy and are handed out by the CPU (a single map above 64 KiB keeps its plain copy); the reference issues
+ *             one blocking cudaMemcpy per array, src/cudaConvolutionFFT.cu:148,231,286.  Cached one-shot calls of the
+ *             reference's demo shape: 120 -> 75 us, profiles/r04s_small_call_latency.txt.  0: plain copies from / into
+ *             the caller's arrays),
  *          "output_region" (which part of the padded window a result map holds, for the plan's
  *             MAX_KERNEL sizes K: 0 (default) the whole FFT_H x FFT_W window as the reference
  *             returns it; 1 "full" = the linear convolution, (DATA + K - 1), what the demo crops by

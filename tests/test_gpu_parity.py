@@ -535,6 +535,59 @@ def test_host_output_streaming_matches_oracle(fc, oracle, ring):
             assert util.rel_err(g, r) < TIGHT
 
 
+@pytest.mark.parametrize("shape", [
+    (64, 8, 5, 10, 4, 3, 0),          # the reference's demo: everything read in place / one copy
+    (256, 256, 1, 31, 31, 4, 0),      # cfg1's image (256 KiB: in place), 324-KiB maps
+    (500, 262, 1, 9, 7, 29, 0),       # image 512 KB (above the in-place limit: one asynchronous copy), 545-KB maps: 29 of
+                                      # them = 4 copies of 7 maps + 1 (two halves of the pinned buffer alternate)
+    (300, 200, 2, 12, 12, 6, 2),      # F = 2, cropped ("same") maps
+    (90, 130, 1, 40, 50, 150, 0),     # kernel groups above 512 KiB (75 and 74 x 8 KB): the plain per-kernel copies beside pinned maps
+])
+def test_small_host_arrays_through_pinned_staging(fc, oracle, shape):
+    """The small-call path (plan option host_pinned, default on): host image / kernels / maps of a few hundred KB travel
+    through pinned buffers of the plan.  Same bits as the plain copies (host_pinned = 0) and the oracle's maps, also when a
+    call is repeated with other data on the same plan (the buffers are refilled behind the GPU work that read them)."""
+    H, W, F, kh, kw, n, region = shape
+    rng = np.random.default_rng(H * 1009 + W)
+    pristine = [rng.standard_normal((H, W, F)).astype(np.float32) for _ in range(2)]
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    if n > 2:
+        ks[n // 2] = rng.standard_normal((max(1, kh - 1), max(1, kw - 2), F)).astype(np.float32)   # a mixed cell: three groups
+    got = {}
+    for pinned in (1, 0):
+        with fc.Plan(H, W, F, kh, kw) as plan:
+            assert plan.get_option("host_pinned") == 1
+            plan.set_option("host_pinned", pinned)
+            if region:
+                plan.set_option("output_region", region)
+            res = []
+            for src in pristine:
+                d = src.copy()
+                plan.set_image(d)
+                d[:] = np.nan                      # the caller's array is its own again as soon as set_image returns
+                res.append(plan.convolve(ks))
+            got[pinned] = res
+    for a, b in zip(got[1], got[0]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    if region == 0:
+        for d, res in zip(pristine, got[1]):
+            for g, r in zip(res, oracle.conv_fft(d, kh, kw, ks)):
+                assert util.rel_err(g, r) < TIGHT
+
+
+def test_one_shot_small_calls_back_to_back(fc, oracle):
+    """cached one-shot calls with changing small inputs (the MATLAB user's loop): every call returns its own maps"""
+    rng = np.random.default_rng(5150)
+    H, W, F, kh, kw, n = 64, 8, 5, 10, 4, 3
+    for rep in range(6):
+        data = rng.standard_normal((H, W, F)).astype(np.float32)
+        ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+        got = fc.cudaConvolutionFFT(data, kh, kw, ks)
+        for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+            assert util.rel_err(g, r) < TIGHT
+
+
 def test_host_output_into_pinned_buffers(fc, oracle):
     """Buffers the caller pinned itself: plain DMA in the direct mode, no ring hop in the ring mode."""
     torch = pytest.importorskip("torch")
