@@ -1224,3 +1224,14 @@ def test_one_shot_plan_cache_blockwise_and_threads(fc, oracle):
             assert util.rel_err(g, r) < TOL
     assert 1 <= fc.cache_stats()["plans"] <= 4
     fc.cache_clear()
+
+
+def test_fuzz_slice(fc, oracle):
+    """a fixed slice of tools/fuzz_gpu.py: random shapes (tiny, strips, sizes sitting just under the specialised lengths),
+    ragged cells, every entry and a random set of plan options per case, each map against the oracle"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(util.ROOT, "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    done, failures, worst = fz.run(seed=7, cases=40, quiet=True)
+    assert done == 40 and not failures and worst < TIGHT
