@@ -2177,10 +2177,46 @@ int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int fe
     (void)fftconv_plan_set_option(p, "verbose", options_verbose(options) ? 1 : 0);
     tm.plan_ms = ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();
+    // The usual small call -- one group of equally sized host kernels that fits the plan's pinned buffer: the kernels are
+    // staged first, so that their column pass rides in the launch of the image's column pass (k_fast_cols_fwd_pair: one
+    // launch fewer on a path that is a chain of five small dependent kernels).  Anything else, and anything that fails a
+    // check, takes the ordinary order below and reports its errors from there.
+    const float* staged_dk = nullptr;
+    if (n_kernel > 0 && kernel_location == FFTCONV_HOST && !p->tiled && p->opt_host_pinned && p->g.fast_fwd && !p->opt_flip_kernels && !p->profile) {
+        bool same = true;
+        for (int k = 0; k < n_kernel && same; k++)
+            same = kernels[k] && out[k] && kernel_h[k] == kernel_h[0] && kernel_w[k] == kernel_w[0];
+        const size_t per = (size_t)feature_dim * (size_t)std::max(kernel_h[0], 0) * (size_t)std::max(kernel_w[0], 0);
+        if (same && per > 0 && per * n_kernel * sizeof(float) <= FC_PIN_INPLACE_BYTES && kernel_h[0] <= p->g.max_kh && kernel_w[0] <= p->g.max_kw &&
+            use_device(p) == 0 && p->pin_k.ensure(per * n_kernel * sizeof(float)) == 0 && p->pin_k.wait() == 0) {
+            for (int j = 0; j < n_kernel; j++) memcpy(p->pin_k.p + per * j * sizeof(float), kernels[j], per * sizeof(float));
+            const long keep_defer = p->opt_defer_prepare;
+            p->opt_defer_prepare = 1;
+            const int rcp = fftconv_plan_prepare_kernels_packed(p, n_kernel, reinterpret_cast<const float*>(p->pin_k.p), kernel_h[0], kernel_w[0]);
+            p->opt_defer_prepare = keep_defer;
+            if (rcp == 0 && p->deferred.on) staged_dk = reinterpret_cast<const float*>(p->pin_k.p);
+            else p->deferred.on = false;
+        }
+    }
     int rc = fftconv_plan_set_image(p, data, FFTCONV_HOST);
     tm.image_ms = ms_since(t1);
     const auto t2 = std::chrono::steady_clock::now();
-    if (!rc) rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, kernel_location, out, FFTCONV_HOST);
+    if (!rc && staged_dk) {
+        Sink sink;
+        sink.ptrs = out;
+        sink.location = FFTCONV_HOST;
+        rc = run_group(p, n_kernel, staged_dk, kernel_h[0], kernel_w[0], sink);
+        const std::string keep_err = g_last_error;
+        const int rcm = p->pin_k.mark(p->stream);
+        if (!rc) rc = rcm; else g_last_error = keep_err;
+        if (!rc) {
+            hipError_t e = hipStreamSynchronize(p->stream);
+            if (e != hipSuccess) rc = fail(FFTCONV_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+        }
+    } else if (!rc) {
+        rc = fftconv_plan_convolve(p, n_kernel, kernels, kernel_h, kernel_w, kernel_location, out, FFTCONV_HOST);
+    }
+    if (rc) p->deferred.on = false;       // (a failed image leaves no request behind in a plan that goes back into the cache)
     tm.convolve_ms = ms_since(t2);
     const auto t3 = std::chrono::steady_clock::now();
     std::string keep = g_last_error;

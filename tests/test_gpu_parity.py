@@ -5,6 +5,7 @@ interface; size-independent properties at BASELINE.json's full sizes.
 Tolerance: max|out - ref| / max|ref| <= 1e-4 per map (north_star: "within 1e-4 relative fp32");
 the fp32 engine is in practice ~1e-6, so the small cases assert 1e-5 to catch regressions."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
