@@ -1424,7 +1424,7 @@ size_t plan_device_bytes(const fftconv_plan* p) {
     size_t b = p->tw_m.bytes() + p->tw_w.bytes() + p->pairs.bytes() + p->S.bytes() + p->A.bytes() + p->Y.bytes() + p->K.bytes() + p->KF.bytes() +
                p->O.bytes() + p->OC.bytes() + p->I.bytes() + p->NS.bytes();
     if (const TiledState* ts = p->tiled) {
-        b += ts->specs.bytes() + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes();
+        b += ts->specs.bytes() + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes() + ts->kstage.bytes();
         if (ts->sub) b += plan_device_bytes(ts->sub);
     }
     return b;
