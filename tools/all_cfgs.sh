@@ -1,6 +1,5 @@
 # one bench line per BASELINE config (device-resident timing), defaults
-# ("cfg2 --overlap": the image transform of step k + 1 on a side stream beside the maps of step k, two spectrum buffers -- what every N > 1 run does; off by default on one GPU because the two cross-stream waits cost cfg1 more than they hide)
-for c in cfg1 cfg2 "cfg2 --overlap" cfg3 "cfg4 --filters 128" cfg5; do python bench.py --config $c --no-cpu-baseline --steps ${STEPS:-10} --warmup 5 --check 2>/dev/null | python -c "
+for c in cfg1 cfg2 cfg3 "cfg4 --filters 128" cfg5; do python bench.py --config $c --no-cpu-baseline --steps ${STEPS:-10} --warmup 5 --check 2>/dev/null | python -c "
 import sys,json
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=j['kernels']
