@@ -21,13 +21,17 @@ TOL = 1e-5
 
 
 def draw_case(rng, max_pixels):
-    cls = rng.choice(["tiny", "small", "small", "medium", "medium", "fast", "fast", "strip"])
+    cls = rng.choice(["tiny", "small", "small", "medium", "medium", "fast", "fast", "strip"] + (["large"] * 8 if max_pixels >= 30_000_000 else []))
     if cls == "tiny":
         H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
     elif cls == "small":
         H, W = int(rng.integers(8, 300)), int(rng.integers(8, 300))
     elif cls == "medium":
         H, W = int(rng.integers(200, 1300)), int(rng.integers(200, 1300))
+    elif cls == "large":    # (--max-mpix >= 30 only) the long transforms and the block-wise planner: one pass up to 8448, blocks from ~4900
+        H, W = int(rng.integers(2300, 6600)), int(rng.integers(2300, 6600))
+        if rng.random() < 0.3:
+            H = int(rng.integers(300, 2300))
     elif cls == "strip":
         H, W = (int(rng.integers(1, 6)), int(rng.integers(100, 3000)))
         if rng.random() < 0.5:
@@ -54,6 +58,8 @@ def draw_case(rng, max_pixels):
         F -= 1
     n = int(rng.integers(1, 13))
     n = max(1, min(n, int(max_pixels * 4 // (fh * fw * F))))
+    if cls == "large":
+        F, n = 1, min(n, 2)
     # a ragged cell: runs of equal sizes (the library groups consecutive kernels of one size into one launch set)
     sizes = []
     while len(sizes) < n:
@@ -63,6 +69,8 @@ def draw_case(rng, max_pixels):
     sizes = sizes[:n]
     entry = str(rng.choice(["one_shot", "plan_host", "plan_host", "plan_device", "two_step"]))
     opts = {"kernel_path": int(rng.choice([0, 0, 0, 1, 2])), "rows_group": int(rng.choice([0, 0, 1, 2, 3, 5]))}
+    if cls == "large":
+        opts = {"kernel_path": 0, "rows_group": 0, "blockwise": int(rng.random() < 0.25)}
     if rng.random() < 0.2 and min(fh, fw) > 80:
         opts["max_transform"] = int(rng.choice([64, 96, 128, 288, 576]))      # forces a block-wise plan
         if opts["max_transform"] < max(mkh, mkw) + 16:
@@ -72,6 +80,12 @@ def draw_case(rng, max_pixels):
     region = int(rng.choice([0, 0, 0, 1, 2, 3]))
     if region == 3 and (H < mkh or W < mkw):
         region = 0
+    if cls == "large":
+        opts.pop("max_transform", None)
+        if not opts["blockwise"]:
+            region = 0                      # the planner may choose blocks: no regions there
+            if rng.random() < 0.2:
+                opts["max_transform"] = int(rng.choice([1152, 2112]))
     return dict(cls=str(cls), H=H, W=W, F=F, mkh=mkh, mkw=mkw, sizes=sizes, entry=entry, opts=opts, runtime=runtime, region=region)
 
 
