@@ -343,6 +343,19 @@ def rank_identity(torch, dev):
             "name": props.name, "device_index": int(dev.index or 0), "pid": os.getpid()}
 
 
+def count_distinct_devices(idents):
+    """(number of distinct devices among the ranks' identities, what the count rests on).  PCI bus ids (or UUIDs) first; a host
+    that reports the same -- or no -- PCI address for every device (virtual functions, some containers) is counted by device
+    index instead: ranks on distinct device indices of one runtime are still distinct devices."""
+    by_pci = len(set((i["host"], i["pci_bus_id"] or i["uuid"] or i["device_index"]) for i in idents))
+    if by_pci == len(idents):
+        return by_pci, "pci_bus_id"
+    by_index = len(set((i["host"], i["device_index"]) for i in idents))
+    if by_index == len(idents):
+        return by_index, "device_index (the PCI ids of the ranks are not distinct)"
+    return by_pci, "pci_bus_id"
+
+
 def numa_prefer_gpu_node(pci_bus_id):
     """Makes the calling thread PREFER the NUMA node the GPU hangs off for the allocations that follow (set_mempolicy
     MPOL_PREFERRED: the pinned images are placed when torch touches / pins them).  Returns what happened, for the JSON."""
@@ -501,14 +514,7 @@ def main():
     if use_dist and world > 1:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
-    distinct_devices = len(set((i["host"], i["pci_bus_id"] or i["uuid"] or i["device_index"]) for i in idents))
-    identity_source = "pci_bus_id"
-    if world > 1 and distinct_devices != world and not args.share_gpu:
-        # a host that reports the same (or no) PCI address for every device (virtual functions, some containers): ranks on
-        # distinct device indices of one runtime are still distinct devices -- say which evidence the count rests on
-        by_index = len(set((i["host"], i["device_index"]) for i in idents))
-        if by_index == world:
-            distinct_devices, identity_source = by_index, "device_index (the PCI ids of the ranks are not distinct)"
+    distinct_devices, identity_source = count_distinct_devices(idents)
     if world > 1 and distinct_devices != world and not args.share_gpu:
         raise SystemExit("bench.py: %d ranks on %d distinct devices (%s); --share-gpu is the one-GPU rehearsal"
                          % (world, distinct_devices, [(i["host"], i["pci_bus_id"]) for i in idents]))

@@ -355,3 +355,27 @@ def test_hot_kernels_do_not_spill():
     spilled = {k: v for k, v in multi_f.items() if v.get("spill", 0) or v.get("scratch", 0)}
     assert not spilled, spilled
     assert not [k for k in rep if "k_fast_rowsI" in k and k.endswith("ELb1EEEvNS_12FastRowsArgsEiiii")]
+
+
+def test_bench_counts_distinct_devices_by_pci_id_then_by_index():
+    """the N > 1 bench refuses to run on fewer distinct devices than ranks (bench.py: count_distinct_devices); a host whose
+    devices all report one PCI address (or none) must not stop an honest run: the count falls back to the device indices"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(util.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def ident(host, pci, idx, uuid=None):
+        return {"host": host, "pci_bus_id": pci, "uuid": uuid, "name": "MI355X", "device_index": idx, "pid": 1000 + idx}
+
+    eight = [ident("n0", "0000:%02x:00.0" % (5 + 16 * i), i) for i in range(8)]
+    assert bench.count_distinct_devices(eight) == (8, "pci_bus_id")
+    same_pci = [ident("n0", "0000:00:00.0", i) for i in range(8)]
+    n, by = bench.count_distinct_devices(same_pci)
+    assert n == 8 and by.startswith("device_index")
+    no_pci = [ident("n0", None, i) for i in range(4)]
+    assert bench.count_distinct_devices(no_pci)[0] == 4
+    shared = [ident("n0", "0000:05:00.0", 0) for _ in range(2)]          # two ranks on one GPU: the rehearsal, refused without --share-gpu
+    assert bench.count_distinct_devices(shared)[0] == 1
+    two_hosts = [ident("n0", "0000:05:00.0", 0), ident("n1", "0000:05:00.0", 0)]
+    assert bench.count_distinct_devices(two_hosts) == (2, "pci_bus_id")
