@@ -123,6 +123,36 @@ def test_emulated_pipeline_matches_oracle(emu, oracle, shape):
         assert util.rel_err(g, r) < 1e-5
 
 
+def _random_small_shapes(count, seed):
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for i in range(count):
+        if i % 4 == 0:      # data + kernel - 1 on or just under the smallest specialised lengths (288 along either axis)
+            kh, kw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            H = 288 - kh + 1 - int(rng.integers(0, 12)) if rng.random() < 0.7 else int(rng.integers(kh, 120))
+            W = 288 - kw + 1 - int(rng.integers(0, 12)) if rng.random() < 0.7 else int(rng.integers(kw, 120))
+        else:
+            H, W = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+            kh, kw = int(rng.integers(1, min(H, 40) + 1)), int(rng.integers(1, min(W, 40) + 1))
+        shapes.append((H, W, int(rng.choice([1, 1, 2, 3, 5])), kh, kw, int(rng.integers(1, 6))))
+    return shapes
+
+
+@pytest.mark.parametrize("shape", _random_small_shapes(24, 2024))
+def test_emulated_pipeline_random_shapes(emu, oracle, shape):
+    """the CPU-tier slice of the randomised parity run (tools/fuzz_gpu.py is its GPU form): seeded random shapes, ragged cells,
+    the kernel bodies through the host emulator against the oracle"""
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape) * 31 + H)
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((int(rng.integers(1, kh + 1)) if rng.random() < 0.4 else kh,
+                               int(rng.integers(1, kw + 1)) if rng.random() < 0.4 else kw, F)).astype(np.float32) for _ in range(n)]
+    rc, got, L = emu_conv(emu, data, kh, kw, ks)
+    assert rc == 0 and L[0] >= H + kh - 1 and L[1] >= W + kw - 1
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
 def test_emulated_oversize_kernel_policy(emu):
     """kernel > MAXK: reproduced (circular, like the reference) when the transform is the ceil16
     window, rejected otherwise"""
