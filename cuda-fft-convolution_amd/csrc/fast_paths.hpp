@@ -96,11 +96,22 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(1152, 8, 12, 12, 192, 2, 12)  \
     X(1088, 17, 4, 16, 192, 2, 2)   \
     X(1088, 17, 4, 16, 192, 2, 4)   \
+    X(960, 6, 16, 10, 192, 2, 4)    \
+    X(960, 6, 16, 10, 192, 2, 7)    \
+    X(960, 6, 16, 10, 192, 2, 16)   \
+    X(864, 4, 12, 18, 192, 4, 4)    \
+    X(864, 4, 12, 18, 192, 4, 12)   \
     X(768, 4, 16, 12, 256, 4, 3)    \
     X(768, 4, 16, 12, 256, 4, 6)    \
     X(768, 4, 16, 12, 256, 4, 16)   \
+    X(672, 4, 12, 14, 192, 4, 3)    \
+    X(672, 4, 12, 14, 192, 4, 12)   \
     X(576, 4, 12, 12, 192, 4, 3)    \
     X(576, 4, 12, 12, 192, 4, 12)   \
+    X(480, 4, 12, 10, 192, 4, 4)    \
+    X(480, 4, 12, 10, 192, 4, 12)   \
+    X(384, 4, 8, 12, 192, 6, 3)     \
+    X(384, 4, 8, 12, 192, 6, 8)     \
     X(288, 4, 6, 12, 192, 8, 3)     \
     X(288, 4, 6, 12, 192, 8, 6)
 #define FC_FAST_ROW_CONFIGS(X) FC_FAST_ROW_CONFIGS_G0(X) FC_FAST_ROW_CONFIGS_G1(X) FC_FAST_ROW_CONFIGS_G2(X)
@@ -254,8 +265,13 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(672, 6, 8, 14, 16, 768)     \
     X(576, 6, 8, 12, 16, 768)     \
     X(544, 2, 17, 16, 16, 544)    \
+    X(480, 6, 8, 10, 16, 768)     \
+    X(432, 6, 6, 12, 16, 576)     \
     X(384, 4, 8, 12, 16, 512)     \
+    X(336, 4, 6, 14, 16, 384)     \
     X(288, 4, 6, 12, 16, 384)     \
+    X(240, 4, 6, 10, 16, 384)     \
+    X(192, 4, 8, 6, 16, 512)      \
     X(144, 4, 6, 6, 16, 384)
 #define FC_FAST_COL_CONFIGS(X) FC_FAST_COL_CONFIGS_G0(X) FC_FAST_COL_CONFIGS_G1(X)
 constexpr int FC_COL_GROUPS = 2;

@@ -132,8 +132,9 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     if (tune.cyclic && (!allow_fast || (H & 1) || max_kh > H || max_kw > W)) return false;
     LengthPrefs prefs;   // the planner prefers lengths with specialised kernels (able to take max_kw)
     if (allow_fast) { prefs.fast_rows = &fast_rows_factor; prefs.fast_cols = &fast_cols_factor; prefs.max_kw = max_kw; }
-    g.Lh = choose_length(H + max_kh - 1, true, g.fft_h, prefs);
-    g.Lw = choose_length(W + max_kw - 1, false, g.fft_w, prefs);
+    // (max_transform caps the search: a cheaper length above it must not turn a size that fits into one that does not)
+    g.Lh = choose_length(H + max_kh - 1, true, g.fft_h, prefs, tune.max_transform);
+    g.Lw = choose_length(W + max_kw - 1, false, g.fft_w, prefs, tune.max_transform);
     if (tune.exact_window || tune.cyclic) {
         if (!length_supported(g.fft_h / 2) || !length_supported(g.fft_w)) return false;
         g.Lh = g.fft_h;

@@ -104,11 +104,13 @@ inline double length_cost(int L, bool real_half, const LengthPrefs& prefs) {
 // Cheapest supported length >= need (even if real_half).  `exact` (>= need, e.g. the ceil16
 // window) wins ties and is preferred when within 10 % of the optimum, so that the common case
 // reproduces the reference's circular-convolution modulus exactly.
-inline int choose_length(int need, bool real_half, int exact, const LengthPrefs& prefs = LengthPrefs()) {
+// `cap` > 0: no length above it is considered (PlanTuning::max_transform); -1 if none fits.
+inline int choose_length(int need, bool real_half, int exact, const LengthPrefs& prefs = LengthPrefs(), int cap = 0) {
     if (need < 1) need = 1;
     int best = -1;
     double bc = 1e30;
     int hi = 2 * need + 32;
+    if (cap > 0) { hi = hi < cap ? hi : cap; if (exact > cap) exact = 0; }
     for (int L = need; L <= hi; L++) {
         if (real_half && (L & 1)) continue;
         double c = length_cost(L, real_half, prefs);

@@ -42,7 +42,13 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 (12, 3750, 1, 3, 60, 1), (3750, 30, 1, 60, 3, 1),       # 3840
                 (10, 5500, 1, 3, 100, 1), (5500, 30, 1, 100, 3, 1),     # 5632
                 (10, 6900, 1, 3, 127, 1), (6900, 30, 1, 127, 3, 1),     # 7040
-                (10, 7500, 1, 3, 127, 1), (7500, 30, 1, 127, 3, 1)]     # 7680
+                (10, 7500, 1, 3, 127, 1), (7500, 30, 1, 127, 3, 1),     # 7680
+                # round 4, late: the small lengths between 288 and 1088 (images of 300 ... 900 pixels), rows / columns / both
+                (20, 350, 1, 5, 30, 2), (350, 28, 2, 30, 5, 1), (340, 350, 1, 31, 31, 2),      # 384
+                (20, 440, 1, 5, 36, 2), (440, 28, 1, 36, 5, 1), (400, 420, 2, 63, 50, 1),      # 480
+                (20, 600, 1, 5, 63, 2), (600, 28, 1, 63, 5, 1), (480, 640, 1, 31, 31, 2),      # 672 (and 576 x 672 for VGA)
+                (20, 800, 1, 5, 63, 2), (800, 28, 3, 63, 5, 1), (800, 800, 1, 63, 63, 1),      # 864
+                (20, 830, 1, 5, 127, 2), (830, 28, 1, 127, 5, 1), (900, 880, 1, 31, 72, 2)]    # 960
 # (path_mode, rows_group): path mode 0 generic kernels, 1 specialised kernels + row-major
 # intermediate, 2 (default) specialised kernels + tiled pair-adjacent intermediate; rows_group -1 auto
 VARIANTS = [(0, -1), (1, -1), (2, -1), (2, 0), (2, 3)]
@@ -436,7 +442,10 @@ def test_gpu_native_window_pairs_vs_generic(fftconv, lh, lw):
                                    # round 4's lengths
                                    (1344, 1760), (1760, 1344), (2560, 3520), (3520, 2560), (5120, 1344), (1344, 5120), (5120, 5120),
                                    (2304, 4608), (4608, 2304), (1920, 2816), (2816, 1920), (3840, 5632), (5632, 3840), (7040, 1920), (1920, 7680),
-                                   (7680, 7040)])
+                                   (7680, 7040),
+                                   # the small lengths of the late round-4 batch
+                                   (384, 480), (480, 384), (672, 864), (864, 672), (960, 384), (384, 960), (480, 960), (864, 864), (672, 288),
+                                   (288, 672), (960, 1152), (1152, 480)])
 def test_gpu_every_fast_length_pair_vs_generic(fftconv, lh, lw):
     """both kernels specialised, every transform length at least once along h and along w, 17
     kernels (multi-map walk + remainder), odd data sizes: specialised path against the generic

@@ -1236,3 +1236,21 @@ def test_fuzz_slice(fc, oracle):
     spec.loader.exec_module(fz)
     done, failures, worst = fz.run(seed=7, cases=40, quiet=True)
     assert done == 40 and not failures and worst < TIGHT
+
+
+@pytest.mark.parametrize("shape", [(398, 322, 3, 75, 92, 5), (850, 600, 1, 29, 86, 3), (954, 1171, 2, 113, 82, 2)])
+def test_blockwise_with_kernels_too_wide_for_the_specialised_block_length(fc, oracle, shape):
+    """max_transform = 288 and kernels wider than the 288-point row kernel takes (72 columns): the blocks are zero-padded
+    (overlap-add) and their transform must stay within the cap -- the planner's preference for a longer length with specialised
+    kernels (384) once made the block plan's creation fail (found by tools/fuzz_gpu.py, seed 5)"""
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape))
+    data = rng.standard_normal((H, W, F)).astype(np.float32)
+    ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for _ in range(n)]
+    ks[-1] = rng.standard_normal((max(1, kh - 3), max(1, kw - 5), F)).astype(np.float32)
+    with fc.Plan(H, W, F, kh, kw, options={"max_transform": 288}) as plan:
+        assert plan.get_option("blockwise") > 1 and max(plan.info.transform_h, plan.info.transform_w) <= 288
+        plan.set_image(data)
+        got = plan.convolve(ks)
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < TIGHT

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import util
 
-FAST_LENGTHS = [288, 576, 768, 1088, 1152, 1344, 1536, 1760, 1920, 2112, 2304]
+FAST_LENGTHS = [288, 384, 480, 576, 672, 768, 864, 960, 1088, 1152, 1344, 1536, 1760, 1920, 2112, 2304]
 TOL = 1e-5
 
 
@@ -184,7 +184,7 @@ def _run(args):
             break
         if args.seconds and time.time() - t0 > args.seconds:
             break
-        if not args.cases and not args.seconds and i >= 20:
+        if not args.cases and not args.seconds and args.only < 0 and i >= 20:
             break
         rng = np.random.default_rng([args.seed, i])
         case = draw_case(rng, int(args.max_mpix * 1e6))
