@@ -36,6 +36,7 @@ def main():
     ks = args.kernels or ([63] if args.quick else [31, 63, 127])
     print("# image HxW, K, window, transform (L_h x L_w), specialised (1 rows | 2 columns), us per step of %d maps, Gpixel-filters/s on the window" % args.filters)
     worst = None
+    worst_mid = None
     rng = np.random.default_rng(1)
     for (H, W) in [(s, s) for s in SQUARE] + RECT:
         for k in ks:
@@ -81,9 +82,13 @@ def main():
                          i.transform_h * i.transform_w / float(fh * fw), "ok" if err < 1e-5 else "CHECKSUM %.2g" % err), flush=True)
                 if min(H, W) >= 1000 and (worst is None or gpx < worst[0]):
                     worst = (gpx, H, W, k)
+                if 500 <= min(H, W) < 1000 and (worst_mid is None or gpx < worst_mid[0]):
+                    worst_mid = (gpx, H, W, k)
             del img, ker, out
     if worst:
         print("# minimum over images of 1000 pixels and more: %.1f Gpx/s at %dx%d K=%d" % worst)
+    if worst_mid:
+        print("# minimum over images of 500 ... 999 pixels (64 maps per step: 80-190 us, launch latency shows): %.1f Gpx/s at %dx%d K=%d" % worst_mid)
 
 
 if __name__ == "__main__":
