@@ -35,6 +35,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 //     R3 = 16 -- every lane of an LDS access group on the same banks (8-way conflict), 4-way at R3 = 24, 2-way at 12 / 20, none at 10,
 //     14, 18, 22, 26.  The R3 = 16 forms went (r04h_row_and_column_configs_ab.txt: rows -11 ... -25 %); 4608 as 8.32.18 and 1152 as
 //     8.8.18 x4 measured SLOWER than the R3 = 24 / 12 forms -- bank conflicts are one term, not the whole cost.
+//   * Late round 4: 384, 480, 672, 864, 960 (images of 300-900 pixels had only 576 and 768 between 288 and 1088) and 1280, 3360 into the
+//     widest gaps above (r04t / r04u size sweeps).  1440 = 8.10.18 x2 (M = 720 = 6.10.12) and 1680 = 10.12.14 x2 (M = 840 = 6.10.14) were
+//     built too and dropped: a 1440 x 1440 transform took 402 us per 64 maps against 375 for 1536 x 1536, 1680 x 1680 as long as 1760 x 1760.
 //   * A search over every admissible (R1, R2, R3, threads) of each length (tools/config_variant.py, r04i_config_search_*.txt) moved
 //     4608 to 12.16.24 (-5 %), 6144 to 16.16.24 (-10 %), 3072 to 16.16.12 (-9 %) and 2560 to 16.16.10 (-14 %): a power-of-two stage 2
 //     of 16 points against 24 / 32.  No rule came out of it -- 5120 as 16.16.20 is 6 % SLOWER than 8.32.20, 4608 as 16.16.18 14 % slower
@@ -71,6 +74,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(3840, 8, 24, 20, 192, 1, 24)  \
     X(3520, 10, 16, 22, 192, 1, 3)  \
     X(3520, 10, 16, 22, 192, 1, 16) \
+    X(3360, 10, 24, 14, 256, 1, 5)  \
+    X(3360, 10, 24, 14, 256, 1, 10) \
+    X(3360, 10, 24, 14, 256, 1, 24) \
     X(3072, 16, 16, 12, 256, 1, 6)  \
     X(3072, 16, 16, 12, 256, 1, 16) \
     X(2816, 8, 16, 22, 192, 1, 3)   \
@@ -91,6 +97,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(1536, 8, 16, 12, 256, 2, 16)  \
     X(1344, 6, 16, 14, 192, 2, 3)   \
     X(1344, 6, 16, 14, 192, 2, 16)  \
+    X(1280, 8, 16, 10, 256, 2, 4)   \
+    X(1280, 8, 16, 10, 256, 2, 7)   \
+    X(1280, 8, 16, 10, 256, 2, 16)  \
     X(1152, 8, 12, 12, 192, 2, 3)   \
     X(1152, 8, 12, 12, 192, 2, 6)   \
     X(1152, 8, 12, 12, 192, 2, 12)  \
@@ -252,7 +261,8 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(2112, 6, 16, 22, 8, 768)    \
     X(2080, 8, 10, 26, 8, 640)    \
     X(1920, 8, 12, 20, 8, 768)    \
-    X(1760, 5, 16, 22, 8, 640)
+    X(1760, 5, 16, 22, 8, 640)    \
+    X(1680, 6, 20, 14, 8, 960)
 #define FC_FAST_COL_CONFIGS_G1(X) \
     X(1536, 8, 16, 12, 8, 1024)    \
     X(1408, 8, 8, 22, 8, 512)    \
@@ -263,6 +273,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(880, 5, 8, 22, 16, 640)     \
     X(768, 8, 8, 12, 16, 1024)     \
     X(672, 6, 8, 14, 16, 768)     \
+    X(640, 8, 8, 10, 16, 1024)    \
     X(576, 6, 8, 12, 16, 768)     \
     X(544, 2, 17, 16, 16, 544)    \
     X(480, 6, 8, 10, 16, 768)     \

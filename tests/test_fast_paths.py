@@ -48,7 +48,10 @@ OTHER_SHAPES = [(256, 256, 1, 31, 31, 1), (1024, 1024, 1, 63, 63, 2), (2048, 204
                 (20, 440, 1, 5, 36, 2), (440, 28, 1, 36, 5, 1), (400, 420, 2, 63, 50, 1),      # 480
                 (20, 600, 1, 5, 63, 2), (600, 28, 1, 63, 5, 1), (480, 640, 1, 31, 31, 2),      # 672 (and 576 x 672 for VGA)
                 (20, 800, 1, 5, 63, 2), (800, 28, 3, 63, 5, 1), (800, 800, 1, 63, 63, 1),      # 864
-                (20, 830, 1, 5, 127, 2), (830, 28, 1, 127, 5, 1), (900, 880, 1, 31, 72, 2)]    # 960
+                (20, 830, 1, 5, 127, 2), (830, 28, 1, 127, 5, 1), (900, 880, 1, 31, 72, 2),    # 960
+                # ... and two lengths into the widest gaps above 1000 (1152 -> 1344, 3072 -> 3520)
+                (20, 1200, 1, 5, 63, 2), (1200, 28, 2, 63, 5, 1),       # 1280
+                (12, 3300, 1, 3, 31, 2), (3300, 28, 1, 31, 5, 1), (12, 3200, 1, 3, 127, 1)]     # 3360
 # (path_mode, rows_group): path mode 0 generic kernels, 1 specialised kernels + row-major
 # intermediate, 2 (default) specialised kernels + tiled pair-adjacent intermediate; rows_group -1 auto
 VARIANTS = [(0, -1), (1, -1), (2, -1), (2, 0), (2, 3)]
@@ -80,8 +83,7 @@ def make_inputs(shape, seed):
 
 @pytest.fixture(scope="module")
 def emu():
-    subprocess.run(["make", "-C", EMU_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    return ctypes.CDLL(os.path.join(EMU_DIR, "libfftconv_emu.so"))
+    return ctypes.CDLL(util.build_emu())
 
 
 def emu_conv(emu, data, mkh, mkw, kernels):
@@ -445,7 +447,8 @@ def test_gpu_native_window_pairs_vs_generic(fftconv, lh, lw):
                                    (7680, 7040),
                                    # the small lengths of the late round-4 batch
                                    (384, 480), (480, 384), (672, 864), (864, 672), (960, 384), (384, 960), (480, 960), (864, 864), (672, 288),
-                                   (288, 672), (960, 1152), (1152, 480)])
+                                   (288, 672), (960, 1152), (1152, 480),
+                                   (1280, 3360), (3360, 1280), (1280, 1280), (3360, 3360), (1280, 576)])
 def test_gpu_every_fast_length_pair_vs_generic(fftconv, lh, lw):
     """both kernels specialised, every transform length at least once along h and along w, 17
     kernels (multi-map walk + remainder), odd data sizes: specialised path against the generic

@@ -9,7 +9,7 @@ import util
 
 pytestmark = pytest.mark.gpu
 
-FAST_LENGTHS = [288, 384, 480, 576, 672, 768, 864, 960, 1152, 1344, 1536, 1760, 1920, 2112, 2304, 2560, 2816, 3072, 3520, 3840, 4224, 4608, 5120, 5632, 6144,
+FAST_LENGTHS = [288, 384, 480, 576, 672, 768, 864, 960, 1152, 1280, 1344, 1536, 1760, 1920, 2112, 2304, 2560, 2816, 3072, 3360, 3520, 3840, 4224, 4608, 5120, 5632, 6144,
                 7040, 7680, 8448]
 
 

@@ -16,9 +16,7 @@ EMU_DIR = os.path.join(util.ROOT, "tests", "emu")
 
 @pytest.fixture(scope="module")
 def emu():
-    so = os.path.join(EMU_DIR, "libfftconv_emu.so")
-    subprocess.run(["make", "-C", EMU_DIR], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    lib = ctypes.CDLL(so)
+    lib = ctypes.CDLL(util.build_emu())
     lib.emu_spectrum_elems.restype = ctypes.c_long
     return lib
 

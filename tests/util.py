@@ -22,8 +22,22 @@ def ceil16(n):
 
 
 def _build(path, target_dir):
-    subprocess.run(["make", "-C", target_dir], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    """make -C target_dir, one process at a time (pytest-xdist workers would otherwise run the same make side by side)"""
+    import fcntl
+    with open(os.path.join(target_dir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-C", target_dir], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     assert os.path.exists(path), path
+
+
+def build_emu():
+    d = os.path.join(ROOT, "tests", "emu")
+    so = os.path.join(d, "libfftconv_emu.so")
+    _build(so, d)
+    return so
 
 
 class Oracle:

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import util
 
-FAST_LENGTHS = [288, 384, 480, 576, 672, 768, 864, 960, 1088, 1152, 1344, 1536, 1760, 1920, 2112, 2304]
+FAST_LENGTHS = [288, 384, 480, 576, 672, 768, 864, 960, 1088, 1152, 1280, 1344, 1536, 1760, 1920, 2112, 2304]
 TOL = 1e-5
 
 
