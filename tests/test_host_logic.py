@@ -407,3 +407,28 @@ def test_bench_counts_distinct_devices_by_pci_id_then_by_index():
     assert bench.count_distinct_devices(shared)[0] == 1
     two_hosts = [ident("n0", "0000:05:00.0", 0), ident("n1", "0000:05:00.0", 0)]
     assert bench.count_distinct_devices(two_hosts) == (2, "pci_bus_id")
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """the round's committed bench line (profiles/r04z_cfg3_bench.json, written by tools/profile_round.sh on the GPU box) carries
+    every key the driver's contract names, the roofline and the CPU baseline objects, and numbers that are consistent with
+    each other"""
+    import json
+    path = os.path.join(util.ROOT, "profiles", "r04z_cfg3_bench.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed bench line")
+    j = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic" and j["higher_is_better"] is True
+    assert "workload" in j["config"] and "4096x4096" in j["config"]["workload"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2      # no wasted re-reads
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
+    # value = maps x padded pixels / step time
+    maps, P = 256, 4224 * 4224
+    assert abs(j["value"] - maps * P / (j["ms_per_step"] * 1e-3) / 1e9) / j["value"] < 1e-3
