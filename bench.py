@@ -258,6 +258,32 @@ def host_output_figures(fc, util, np, torch, dev, cases=(("cfg2", 16), ("cfg3", 
         res[cfg + ("/%d maps" % n if n != CONFIGS[cfg][5] else "")] = r
         del outs
         fc.cache_clear()
+    # the sizes a MATLAB user of the reference calls it with: the demo's shape (demoCudaConvolutionFFT.m:37-42) and cfg1 -- latency of a
+    # cached one-shot call (microseconds, median of 200, through the ctypes mirror; caller buffers reused), with the small host arrays
+    # through the plan's pinned staging buffers (option host_pinned, the default) and with one runtime copy per array (host_pinned 0)
+    small = {}
+    for name, (H, W, F, kh, kw, n) in (("demo 64x8x5 (x) 3 x 10x4x5", (64, 8, 5, 10, 4, 3)), ("cfg1 256x256 (x) 31x31", (256, 256, 1, 31, 31, 1))):
+        img, ks = util.synth(77, H, W, F, kh, kw, n)
+        outs = fc.cudaConvolutionFFT(img, kh, kw, ks)
+        ts = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            fc.cudaConvolutionFFT(img, kh, kw, ks, out=outs)
+            ts.append((time.perf_counter() - t0) * 1e6)
+        e = {"one_shot_cached_us": _median(ts), "library_us": fc.last_call_timing()["total_ms"] * 1e3}
+        with fc.Plan(H, W, F, kh, kw) as p:
+            for pinned in (1, 0):
+                p.set_option("host_pinned", pinned)
+                p.set_image(img); p.convolve(ks, out=outs)
+                ts = []
+                for _ in range(200):
+                    t0 = time.perf_counter()
+                    p.set_image(img); p.convolve(ks, out=outs)
+                    ts.append((time.perf_counter() - t0) * 1e6)
+                e["kept_plan_us" if pinned else "kept_plan_plain_copies_us"] = _median(ts)
+        small[name] = e
+    res["small_calls"] = small
+    fc.cache_clear()
     return res
 
 
