@@ -497,6 +497,12 @@ def main():
                          "default run reports this figure as value_kernels_resident)")
     ap.add_argument("--no-host-output", action="store_true", help="skip the host-in / host-out figures (host_output)")
     ap.add_argument("--no-multi-feature", action="store_true", help="skip the F > 1 figures (multi_feature)")
+    ap.add_argument("--dynamic-tiles", type=int, default=-1,
+                    help="plan option dynamic_tiles: the persistent column kernels take their tiles from a queue (1) or by the static "
+                         "deal (0: A/B); -1 = the library's default (1)")
+    ap.add_argument("--contend", default=None, metavar="K[,LDS_KB]",
+                    help="A/B: K workgroups of tools/microbench/cu_hog (each holding LDS_KB of LDS, default 4) sit on the GPU during the "
+                         "timed steps -- a stand-in for a collective's channels co-resident with the step (single GPU)")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the broadcast code path even with one rank (self-test of the N > 1 step on a 1-GPU box)")
     args = ap.parse_args()
@@ -582,6 +588,32 @@ def main():
         plan.set_option("rows_group", args.rows_group)
     if args.kernel_chunk_mb:
         plan.set_option("kernel_chunk_mb", args.kernel_chunk_mb)
+    if args.dynamic_tiles >= 0:
+        plan.set_option("dynamic_tiles", args.dynamic_tiles)
+    hog = None
+    hog_cfg = None
+    side_work = None
+    if args.contend:
+        import ctypes
+        parts = [int(x) for x in args.contend.split(",")]
+        hog_cfg = {"workgroups": parts[0], "lds_kb": parts[1] if len(parts) > 1 else 4, "per_step_us": parts[2] if len(parts) > 2 else 0}
+        if hog_cfg["workgroups"] > 0:
+            hog_path = os.path.join(ROOT, "tools", "microbench", "libcuhog.so")
+            if not os.path.exists(hog_path):
+                raise SystemExit("bench.py --contend: %s is not built (python -c 'import __graft_entry__ as g; g.build()')" % hog_path)
+            hog = ctypes.CDLL(hog_path)
+            hog.cu_hog_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            if hog_cfg["per_step_us"] > 0:
+                # one launch per step on the side stream, where the broadcast of the N > 1 pipeline goes: beside the previous step's maps
+                hog_lib = hog
+
+                def side_work(stream_handle):
+                    rc = hog_lib.cu_hog_run(stream_handle, hog_cfg["workgroups"], 256, hog_cfg["lds_kb"] << 10, hog_cfg["per_step_us"])
+                    if rc:
+                        raise SystemExit("bench.py --contend: cu_hog_run failed (%d)" % rc)
+            elif hog_cfg["lds_kb"] > 8:
+                raise SystemExit("bench.py --contend: workgroups that hold more than 8 KB of LDS for the whole timed region would block "
+                                 "the persistent kernels until the stop that follows them; give a per-step duration (K,LDS_KB,US)")
     # placement tuning (untimed set-up, like a plan's measuring): only where launches are long enough to tell 4 % apart
     # (5 candidates since round 4: with 3 one box in five still ended in the slow state, every candidate in a slow region)
     tune_k = args.tune_placement if args.tune_placement >= 0 else (5 if min(args.batch_maps or 64, max(nf, 1)) * P >= 5e8 else 0)
@@ -589,7 +621,7 @@ def main():
         plan.set_option("tune_placement", tune_k)
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
     # the next image's H2D copy (streamed mode)
-    overlap = streamed or ((use_dist or args.overlap) and not args.no_overlap)
+    overlap = streamed or ((use_dist or args.overlap or side_work is not None) and not args.no_overlap)
     # the kernels' column pass rides in the image transform's launch where that transform follows on the plan's own stream
     defer_prepare = streamed or not overlap
     # the step's kernels are uploaded inside the step, from pinned host memory, double-buffered on an upload stream
@@ -618,7 +650,8 @@ def main():
     else:
         conv = mg.FilterShardedConvolver(engine, dist if use_dist else None, rank, world, nf_total, src=0,
                                          depth=2 if overlap else 1, always_collective=args.force_collective,
-                                         time_broadcast=("event" if backend == "nccl" else "wall") if use_dist else None)
+                                         time_broadcast=("event" if backend == "nccl" else "wall") if use_dist else None,
+                                         side_work=side_work)
 
         def run_steps(k):
             conv.run([img_d] * k)
@@ -691,6 +724,11 @@ def main():
     else:
         conv.upload_ms(reset=True)
     uploads0 = engine.uploads
+    if hog is not None and side_work is None:       # the other kernel takes its CUs on the idle GPU, then the timed steps run beside it
+        rc = hog.cu_hog_start(hog_cfg["workgroups"], 256, hog_cfg["lds_kb"] << 10, 20000)
+        if rc:
+            raise SystemExit("bench.py --contend: cu_hog_start failed (%d)" % rc)
+        time.sleep(0.002)
     t0 = time.perf_counter()
     if graph is not None:
         for _ in range(args.steps):
@@ -699,6 +737,18 @@ def main():
         run_steps(args.steps)
     torch.cuda.synchronize(dev)
     dt_rank = time.perf_counter() - t0          # this rank's own time (the headline is the max over ranks, behind the barrier)
+    if hog is not None:
+        import ctypes
+        ncu, ran = ctypes.c_int(0), ctypes.c_float(0)
+        if side_work is None:
+            rc = hog.cu_hog_stop(ctypes.byref(ncu), ctypes.byref(ran))
+            hog_cfg.update({"distinct_cus_held": ncu.value, "held_ms": ran.value, "stop_rc": rc,
+                            "covered_timed_region": bool(ran.value >= dt_rank * 1e3)})
+        else:
+            rc = hog.cu_hog_last_places(ctypes.byref(ncu))
+            hog_cfg.update({"distinct_cus_held": ncu.value, "stop_rc": rc, "covered_timed_region": True})
+            conv.side_work = None          # the passes below (per-kernel timing, checks) run alone
+        hog = None
     barrier()
     dt = time.perf_counter() - t0
     kernel_uploads_timed = engine.uploads - uploads0
@@ -888,6 +938,8 @@ def main():
                                   else "resident in HBM",
                        "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps, "settle_s": args.settle_s,
                        "tune_placement": {"candidates": plan.get_option("tuned_candidates"), "kept": plan.get_option("tuned_best")} if tune_k > 1 else None,
+                       "dynamic_tiles": plan.get_option("dynamic_tiles"),
+                       "contention": hog_cfg,
                        "images_per_step": args.images if streamed else 1,
                        "parallelism": ("images x%d, streamed H2D" % world) if streamed else
                                       ("filters x%d + 1 bcast per step" % world if world > 1 else "single GPU")},

@@ -42,7 +42,8 @@ struct ColCfg {
     static constexpr int OFF_WH = OFF_T1 + m1;
     static constexpr int OFF_WL = OFF_WH + NWH;
     static constexpr int OFF_PAIR = OFF_WL + 32;                          // NPE dwords = (NPE + 1) / 2 c32
-    static constexpr int LDS_ELEMS = OFF_PAIR + (NPE + 1) / 2;
+    static constexpr int OFF_QUEUE = OFF_PAIR + (NPE + 1) / 2;            // 4 ints of the dynamic tile queue (TileQueue below)
+    static constexpr int LDS_ELEMS = OFF_QUEUE + 2;
     static_assert(R1 * R2 * R3 == M, "radices must multiply to M");
     static_assert(M % 2 == 0 && T % 2 == 0, "even M and T");
     static_assert(NB3 * T == NT, "one stage-3 butterfly per thread");
@@ -51,6 +52,48 @@ struct ColCfg {
     static_assert(LP >= M + 1 && LP % 16 == 2, "column pitch");
     static_assert(LDS_ELEMS * 8 <= 160 * 1024, "LDS budget");
 };
+
+// Dynamic tile queue of the persistent column kernels (plan option "dynamic_tiles").  The static deal -- workgroup b
+// owns tiles b, b + grid, ... -- assumes that every workgroup of the grid starts at once and runs at the same speed.
+// Beside another kernel (the RCCL broadcast of the next step's image spectrum on the ranks of a multi-GPU run:
+// src/cudaConvFFTDataStreams.cu:279-289,338-447 is the intent) that does not hold: a workgroup here needs nearly a whole CU's
+// LDS, so one whose CU is taken starts only when the other kernel has left, and its 1 / grid of the launch's tiles waits with it.
+// With the queue a workgroup takes its next tile when it is ready for one: eight counters (one 128-byte line each), one
+// per XCD; ticket k of XCD v is tile ((k >> shift) * 8 + v) << shift | (k & mask) -- chunks of 2^shift consecutive tiles
+// dealt to the XCDs in turn, so the workgroups of an XCD still walk a run of adjacent tiles together through one L2 (adjacent
+// tiles share the 128-byte lines of the intermediate).  A workgroup whose XCD has run out takes tickets of the others (one
+// look at the seven other counters, then a take from the first that has tiles left), so a slower XCD is helped out at the
+// end.  The ticket of the tile after next is requested at the start of a tile and read after its last stage: the software
+// pipeline (gather of the next tile behind the transform of this one) is as in the static deal.  The counters are zero
+// between launches: the plan zeroes them once, and the workgroup that leaves a launch LAST (an exit count beside the
+// counters) zeroes them again -- no memset command per launch (a hipMemsetAsync ahead of every launch serialised the
+// plan's stream against the side stream's kernel in most runs: profiles/r05a_contention_ab_memset_per_launch.txt).
+constexpr int FC_QUEUE_STRIDE = 32;                    // ints between two counters: a 128-byte line each
+constexpr int FC_QUEUE_COUNTERS = 10;                  // 8 XCD counters of the output kernel + 2 plain counters of the forward column kernels
+constexpr int FC_QUEUE_EXIT = 16;                      // word of a counter's line that counts the workgroups that have left the launch
+constexpr int FC_QUEUE_WORDS = FC_QUEUE_COUNTERS * FC_QUEUE_STRIDE;
+FC_HD int queue_tile(int v, int k, int shift) { return ((((k >> shift) << 3) + v) << shift) + (k & ((1 << shift) - 1)); }
+// thread 0 only: a tile of another XCD's queue, or n if none has any left.  Counters only grow, so a counter seen
+// exhausted stays exhausted and one pass is complete; one seen with tiles left may have lost them since (the take says).
+FC_HD int queue_steal(int* q, int shift, int home, int n) {
+    int seen[8];
+    static_for<1, 8>([&](auto i_) { seen[decltype(i_)::value] = FC_QUEUE_PEEK(q + ((home + decltype(i_)::value) & 7) * FC_QUEUE_STRIDE); });
+    for (int i = 1; i < 8; i++) {
+        const int v = (home + i) & 7;
+        if (queue_tile(v, seen[i], shift) >= n) continue;
+        const int tl = queue_tile(v, FC_QUEUE_TAKE(q + v * FC_QUEUE_STRIDE), shift);
+        if (tl < n) return tl;
+    }
+    return n;
+}
+
+// thread 0 of a workgroup that takes no more tiles: the last one out zeroes the `n` counters from q on for the next launch
+FC_HD void queue_leave(int* q, int n, int nwg) {
+    if (FC_QUEUE_TAKE(q + FC_QUEUE_EXIT) == nwg - 1) {
+        for (int v = 0; v < n; v++) FC_QUEUE_PUT(q + v * FC_QUEUE_STRIDE, 0);
+        FC_QUEUE_PUT(q + FC_QUEUE_EXIT, 0);
+    }
+}
 
 struct FastColsArgs {
     const c32* Y;            // [n][i][y_pitch]
@@ -80,6 +123,10 @@ struct FastColsArgs {
     // full rounds only; the `tail_tiles` tiles from `tail_first` on are cut into 1 << slice_shift column slices each and
     // dealt one slice per workgroup.  All three are 0 otherwise.
     int tail_first, tail_tiles, slice_shift;
+    // dynamic tile queue (see above): 8 counters FC_QUEUE_STRIDE ints apart, zero at launch; nullptr: the static deal.
+    // Unsliced launches only.
+    int* queue;
+    int queue_shift;
 };
 
 template <class C>
@@ -87,6 +134,7 @@ struct ColState {
     c32x2 pre[C::UPT];   // gather of the next tile
     c32x2 pre_ny;        // ... its Nyquist row (threads < T/2)
     int off[C::UPT];     // Y row offsets (or, precombined, LDS landing positions) of this thread's gather units
+    int tk;              // thread 0, dynamic tile queue: the ticket requested at the start of the tile
 };
 
 // tiled intermediate (pair-adjacent rows, merge while landing): rows of bins k and M-k come as pairs
@@ -96,6 +144,7 @@ struct ColPairState {
     static constexpr int RNDU = (NPU + C::NT - 1) / C::NT;
     c32x2 pa[RNDU];      // row of bin k (or DC / middle)
     c32x2 pb[RNDU];      // row of bin M-k (or Nyquist / padding)
+    int tk;              // thread 0, dynamic tile queue: the ticket requested at the start of the tile
 };
 
 // Bin pair a gather unit takes (tiled intermediate).  With 4-column tiles a 16-lane LDS access group lands 8 pairs x 2 column
@@ -141,9 +190,12 @@ FC_HD int pair_of_unit(int u) {
 // takes one column SLICE of a tile of the last, partial round -- the same phases with the lanes of the other columns
 // switched off -- so that round costs a fraction of a tile time instead of a whole one (cfg2: 16 maps x 68 tiles = 1088
 // tiles on 256 workgroups are 4 full rounds + 64 tiles; as 256 quarter tiles the fifth round moves a quarter of the bytes).
-template <class C, bool TILED, bool SLICED = false, class Ctx>
+// DYN: tiles from the dynamic queue (g.queue; see TileQueue above) instead of the static deal -- a template parameter so that
+// the static kernel carries none of the queue's scalar state (as a run-time switch it cost 6 SGPRs and 44 SGPR spills).
+template <class C, bool TILED, bool SLICED = false, bool DYN = false, class Ctx>
 FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int nwg) {
     static_assert(!SLICED || TILED, "column slices exist for the tiled intermediate only");
+    static_assert(!(SLICED && DYN), "the sliced tail round is dealt statically");
     static_assert(!SLICED || (C::T & (C::T - 1)) == 0, "column slices: the tile width must be a power of two (slices of whole column pairs)");
     constexpr bool PLAND = TILED;
     constexpr int M = C::M, R1 = C::R1, R2 = C::R2, R3 = C::R3, T = C::T, NT = C::NT, LP = C::LP, m1 = C::m1;
@@ -176,7 +228,28 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     // columns [lo, hi) of tile it that this workgroup transforms (the whole tile unless it is the slice round)
     auto cols_lo = [&](int it) -> int { return (SLICED && it == full_rounds) ? (wg_x & ((1 << g.slice_shift) - 1)) * (T >> g.slice_shift) : 0; };
     auto cols_hi = [&](int it) -> int { return (SLICED && it == full_rounds) ? cols_lo(it) + (T >> g.slice_shift) : T; };
-    const int first_tile = tile_of(0);
+    // dynamic tile queue (TileQueue above; never with SLICED): qs[0] = the tile after next (written by thread 0 behind the last
+    // stage of a tile, read by everybody after that phase's barrier), qs[1] = this workgroup's first tile, qs[2] = 1 once the
+    // home XCD's counter has run out (then tiles come from the other XCDs' counters, without the early request)
+    constexpr bool dyn = DYN;
+    [[maybe_unused]] int* qs = reinterpret_cast<int*>(lds + C::OFF_QUEUE);
+    [[maybe_unused]] const int home = dyn ? FC_XCC_ID(wg) : 0;
+    [[maybe_unused]] int dyn_next = n_total;
+    if constexpr (dyn) {
+        ctx.phase([&](int t, State&) {
+            if (t == 0) {
+                int* qh = g.queue + home * FC_QUEUE_STRIDE;
+                const int k0 = FC_QUEUE_TAKE(qh), k1 = FC_QUEUE_TAKE(qh);
+                int t0 = queue_tile(home, k0 < k1 ? k0 : k1, g.queue_shift), t1 = queue_tile(home, k0 < k1 ? k1 : k0, g.queue_shift);
+                int out_of_home = 0;
+                if (t0 >= n_total) { out_of_home = 1; t0 = queue_steal(g.queue, g.queue_shift, home, n_total); }
+                if (t1 >= n_total) { out_of_home = 1; t1 = t0 < n_total ? queue_steal(g.queue, g.queue_shift, home, n_total) : n_total; }
+                qs[1] = t0; qs[0] = t1; qs[2] = out_of_home;
+            }
+        });
+        dyn_next = FC_UNIFORM(qs[0]);
+    }
+    const int first_tile = dyn ? FC_UNIFORM(qs[1]) : tile_of(0);
     [[maybe_unused]] int cur_lo = cols_lo(0), cur_hi = cols_hi(0), nxt_lo = 0, nxt_hi = T;
 
     // part: 0 = the whole gather; 1 / 2 (mode 3) = its first / second half of rounds -- a CU cannot
@@ -299,12 +372,18 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     // (the landing of mode 3 reads the tables written above: it needs the barrier in between)
     if (first_tile < n_total) ctx.phase([&](int t, State& st) { land_gather(t, st, cur_lo, cur_hi); });
 
+    [[maybe_unused]] int dyn_tile = first_tile;
     for (int it = 0;; it++) {
-        const int tile = tile_of(it);
+        const int tile = dyn ? dyn_tile : tile_of(it);
         if (tile >= n_total) break;
         const int kernel = tile / g.tiles_per_kernel;
         const int w0 = g.w_first + (tile - kernel * g.tiles_per_kernel) * T;
-        const int next = tile_of(it + 1);
+        const int next = dyn ? dyn_next : tile_of(it + 1);
+        // dynamic queue: the ticket of the tile after next is requested now (ahead of the gather loads: the memory counter is in
+        // order) and read in C4, behind the wait for the gather that is there anyway
+        if constexpr (dyn) if (next < n_total) ctx.phase_nosync([&](int t, State& st) {
+            if (t == 0 && !qs[2]) st.tk = FC_QUEUE_TAKE(g.queue + home * FC_QUEUE_STRIDE);
+        });
         if constexpr (SLICED) { cur_lo = cols_lo(it); cur_hi = cols_hi(it); nxt_lo = cols_lo(it + 1); nxt_hi = cols_hi(it + 1); }
         FC_COLS_STAMP(0);
 
@@ -408,13 +487,24 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         float* out = g.out + (size_t)kernel * g.out_kernel_stride;
         const int pair_lo = g.h_lo >> 1;                                 // complex pairs [pair_lo, pair_lo + nout) of a column are stored
         const unsigned nout = (unsigned)((g.fft_h - g.h_lo) >> 1);
-        ctx.phase([&](int t, State&) {
+        ctx.phase([&](int t, [[maybe_unused]] State& st) {
 #if !FC_COLS_NO_PREWAIT
             // the next tile's gather (issued in C1) has had two stages to arrive: take it off the
             // memory counter now, so that landing it does not wait for the stores below
             FC_WAIT_VMEM();
 #endif
             FC_COLS_STAMP(4);
+            if constexpr (dyn) {
+                if (next < n_total && t == 0) {   // the tile after next: the ticket requested in C1, or another XCD's
+                    int tl = n_total;
+                    if (!qs[2]) {
+                        tl = queue_tile(home, st.tk, g.queue_shift);
+                        if (tl >= n_total) qs[2] = 1;
+                    }
+                    if (tl >= n_total) tl = queue_steal(g.queue, g.queue_shift, home, n_total);
+                    qs[0] = tl;
+                }
+            }
             FC_NOUNROLL
             for (int r = 0; r < C::RND1; r++) {   // one butterfly at a time: the prefetched tile stays in registers
                 const int idx = t + NT * r;
@@ -441,12 +531,14 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 }
             }
         });
+        if constexpr (dyn) { dyn_tile = next; dyn_next = next < n_total ? FC_UNIFORM(qs[0]) : n_total; }
 
         FC_COLS_STAMP(5);
         // C5: the prefetched tile lands in LDS
         if (next < n_total) ctx.phase([&](int t, State& st) { land_gather(t, st, nxt_lo, nxt_hi); });
         FC_COLS_STAMP(6);
     }
+    if constexpr (dyn) ctx.phase_nosync([&](int t, State&) { if (t == 0) queue_leave(g.queue, 8, nwg); });
 }
 
 }  // namespace fc

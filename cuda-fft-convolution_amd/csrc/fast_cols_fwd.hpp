@@ -32,9 +32,13 @@ struct FastColsFwdArgs {
     const c32* tw1;          // w_M^j, j < m1
     const c32* tw2;          // stage-2 table [(c-1)*R3 + b]
     const PairEntry* pairs;  // NPE entries (w = w_N^k), positions in this plan's order
+    int* queue;              // dynamic tile queue (fast_cols.hpp): ONE counter, zero at launch (the last workgroup out zeroes it again)
+                             // -- the tiles are taken in order, one ahead; nullptr: workgroup b owns tiles b, b + grid, ...
 };
 
-struct ColFwdState {};   // nothing lives across phases
+struct ColFwdState {
+    int tk;                  // thread 0, dynamic tile queue: the ticket requested at the start of the tile
+};
 
 // NZ2 < R2: pruned variant (see header); NZ2 == R2: any h_in <= 2M
 template <class C, int NZ2, class Ctx>
@@ -48,6 +52,10 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
     c32* wl = lds + C::OFF_WL;
     unsigned* ppos = reinterpret_cast<unsigned*>(lds + C::OFF_PAIR);
     const int nz = (g.h_in + 1) / 2;   // non-zero packed complex samples per column
+    // dynamic tile queue (fast_cols.hpp): qs[0] = the tile after this one (requested at the start of a tile by thread 0, written in
+    // F4, read by everybody behind F5's barrier), qs[1] = the first tile
+    const bool dyn = g.queue != nullptr;
+    int* qs = reinterpret_cast<int*>(lds + C::OFF_QUEUE);
 
     ctx.phase([&](int t, State&) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
@@ -58,16 +66,27 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
             if ((i & 31) == 0) wh[i >> 5] = e.w;
             if (i < 32) wl[i] = e.w;
         }
+        if (dyn && t == 0) {       // the first two tiles of this workgroup
+            const int k0 = FC_QUEUE_TAKE(g.queue), k1 = FC_QUEUE_TAKE(g.queue);
+            qs[1] = k0 < k1 ? k0 : k1;
+            qs[0] = k0 < k1 ? k1 : k0;
+        }
     });
 
-    for (int tile = wg; tile < g.ntiles; tile += nwg) {
+    int dyn_next = dyn ? FC_UNIFORM(qs[0]) : 0;
+    const int first_tile = dyn ? FC_UNIFORM(qs[1]) : wg;
+    // (everybody has read the two slots before thread 0 may write them again: a workgroup without a tile runs straight into
+    //  the second body of the image + kernels launch, whose prologue fills them anew)
+    if (dyn) ctx.phase([&](int, State&) {});
+    for (int tile = first_tile; tile < g.ntiles;) {
         const int plane = tile / g.tiles_per_plane;
         const int c0 = (tile - plane * g.tiles_per_plane) * T;
         const float* in = g.in + (size_t)plane * g.in_plane_stride;
         c32* out = g.out + (size_t)plane * g.out_plane_stride;
 
         // F1: packed load z[n] = x[2n] + i x[2n+1] fused with stage 1 (radix R1, sub-length m1)
-        ctx.phase([&](int t, State&) {
+        ctx.phase([&](int t, [[maybe_unused]] State& st) {
+            if (dyn && t == 0 && dyn_next < g.ntiles) st.tk = FC_QUEUE_TAKE(g.queue);
             auto sample = [&](const float* col, int n) -> c32 {
                 float x0 = (2 * n < g.h_in) ? col[2 * n] : 0.f;
                 float x1 = (2 * n + 1 < g.h_in) ? col[2 * n + 1] : 0.f;
@@ -170,7 +189,8 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
         });
 
         // F4: split the packed transform into the spectrum of the real columns, in place
-        ctx.phase([&](int t, State&) {
+        ctx.phase([&](int t, [[maybe_unused]] State& st) {
+            if (dyn && t == 0 && dyn_next < g.ntiles) qs[0] = st.tk;
             FC_NOUNROLL
             for (int r = 0; r < C::RNDP; r++) {
                 const int idx = t + NT * r;
@@ -210,7 +230,14 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
                 if (c0 + col < g.ncols) out[(size_t)p * g.out_pitch + c0 + col] = lds[col * LP + p];
             }
         });
+        if (dyn) {
+            tile = dyn_next;
+            dyn_next = dyn_next < g.ntiles ? FC_UNIFORM(qs[0]) : g.ntiles;
+        } else {
+            tile += nwg;
+        }
     }
+    if (dyn) ctx.phase_nosync([&](int t, State&) { if (t == 0) queue_leave(g.queue, 1, nwg); });
 }
 
 }  // namespace fc

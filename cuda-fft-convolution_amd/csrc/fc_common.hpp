@@ -93,6 +93,22 @@
 #define FC_WAIT_VMEM() ((void)0)
 #endif
 
+// Dynamic tile queue of the persistent column kernels (fast_cols.hpp: TileQueue): one returning agent-scope add on a
+// counter word, a relaxed agent-scope load of one, and the XCD a workgroup runs on (HW_REG_XCC_ID bits 3:0 -- read, not
+// inferred from the block index: with another kernel co-resident the round-robin placement is not what it is alone).  On the
+// host (tests/emu: workgroups run one after the other) they are a plain increment / load and the block index modulo 8.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FC_QUEUE_TAKE(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FC_QUEUE_PEEK(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FC_QUEUE_PUT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FC_XCC_ID(wg) ((int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u))
+#else
+#define FC_QUEUE_PUT(p, v) (*(p) = (v))
+#define FC_QUEUE_TAKE(p) ((*(p))++)
+#define FC_QUEUE_PEEK(p) (*(p))
+#define FC_XCC_ID(wg) ((wg) & 7)
+#endif
+
 namespace fc {
 
 // A complex value.  Under clang (hipcc: device code and the host side of the library) it is a

@@ -425,6 +425,8 @@ struct fftconv_plan {
     DevBuf<c32> fc_tw1, fc_tw2;
     DevBuf<PairEntry> fc_pairs;
     DevBuf<int> fc_rowoff, fc_pair_row_of;
+    DevBuf<int> queue;                    // counters of the dynamic tile queue (option "dynamic_tiles"; allocated when it is first set)
+    long opt_dynamic_tiles = 0;           // 1: the persistent column kernels take their tiles from a queue (fast_cols.hpp: TileQueue)
     DevBuf<int> nat_row_of, nat_col_of;   // natural-order spectrum exchange (uploaded on first use)
     DevBuf<c32> NS;                       // its device staging for host callers
     int num_cus = 256;
@@ -511,7 +513,7 @@ struct fftconv_plan {
         S.release(); A.release(); Y.release(); K.release(); KF.release(); O.release(); OC.release(); I.release();
         fr_tw1.release(); fr_tw2.release(); fr_map.release();
         fc_tw1.release(); fc_tw2.release(); fc_pairs.release(); fc_rowoff.release(); fc_pair_row_of.release();
-        nat_row_of.release(); nat_col_of.release(); NS.release();
+        nat_row_of.release(); nat_col_of.release(); NS.release(); queue.release();
         pin_img.release(); pin_k.release(); pin_out.release();
         for (int h = 0; h < 2; h++) { if (pin_out_done[h]) (void)hipEventDestroy(pin_out_done[h]); pin_out_done[h] = nullptr; }
     }
@@ -687,7 +689,7 @@ int launch_kernel_cols(fftconv_plan* p, const float* dk, int a0, int na, int kh,
     if (int rc = p->prof_begin(PK_KERNEL_COLS, na)) return rc;
     if (g.fast_fwd) {
         FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dk + (size_t)a0 * g.F * kh * kw, (size_t)kh * kw, kh, kh, kw, na * g.F,
-                                                p->A.p, (size_t)g.rows * a_pitch_for(kw), a_pitch_for(kw));
+                                                p->A.p, (size_t)g.rows * a_pitch_for(kw), a_pitch_for(kw), true);
         HIP_TRY(launch_fast_cols_fwd(g.M, g.fast_cols.T, fast_cols_fwd_pruned_ok(g.fast_cols, kh), fa, p->num_cus, p->stream));
     } else {
         ColsR2CArgs ka = kernel_cols_args(g, p->t, p->d, dk + (size_t)a0 * g.F * kh * kw, kh, kw, p->A.p);
@@ -1644,6 +1646,13 @@ int plan_create_internal(fftconv_plan** plan, int data_h, int data_w, int featur
             if ((rc = p->fc_pair_row_of.ensure(ft.pair_row_of.size()))) break;
             if ((rc = cp(p->fc_pair_row_of.p, ft.pair_row_of.data(), ft.pair_row_of.size() * sizeof(int)))) break;
             p->d.fc_pair_row_of = p->fc_pair_row_of.p;
+            // dynamic tile queue of the persistent column kernels: on by default (option "dynamic_tiles"; alone on the GPU it
+            // measures equal or up to 2 % faster than the static deal, beside another kernel it loses half as much:
+            // profiles/r05a_contention_ab.txt).  Zeroed once; every launch leaves the counters at zero.
+            if ((rc = p->queue.ensure(FC_QUEUE_WORDS))) break;
+            if (hipMemset(p->queue.p, 0, FC_QUEUE_WORDS * sizeof(int)) != hipSuccess) { rc = fail(FFTCONV_ERR_HIP, "hipMemset of the tile queue failed"); break; }
+            p->opt_dynamic_tiles = 1;
+            p->d.queue = p->queue.p;
         }
         if (p->g.fast_rows.ok && p->g.F == 1) {   // resident workgroups per CU of the multi-map row kernel: what rows_group_auto deals over
             FastRowsArgs qa = fast_rows_args(p->g, p->d, nullptr, p->g.max_kw, nullptr, nullptr);
@@ -1767,15 +1776,15 @@ int fftconv_plan_set_image(fftconv_plan* plan, const float* data, int location) 
         const auto pd = p->deferred;
         p->deferred.on = false;
         FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dimg, (size_t)g.H * g.W, g.H, g.H, g.W, g.F, sgen,
-                                                (size_t)g.rows * g.s_pitch, g.s_pitch);
+                                                (size_t)g.rows * g.s_pitch, g.s_pitch, false);
         FastColsFwdArgs fk = fast_cols_fwd_args(g, p->d, pd.dk, (size_t)pd.kh * pd.kw, pd.kh, pd.kh, pd.kw, pd.na * g.F, p->A.p,
-                                                (size_t)g.rows * a_pitch_for(pd.kw), a_pitch_for(pd.kw));
+                                                (size_t)g.rows * a_pitch_for(pd.kw), a_pitch_for(pd.kw), true);
         FC_VERBOSE(p, "image columns (%d tiles) and the columns of %d kernels (%d tiles) in one launch", fa.ntiles, pd.na, fk.ntiles);
         HIP_TRY(launch_fast_cols_fwd_pair(g.M, g.fast_cols.T, fa, fk, fast_cols_fwd_pruned_ok(g.fast_cols, pd.kh), p->num_cus, p->stream));
         p->prepared.dk = pd.dk; p->prepared.n = pd.n; p->prepared.kh = pd.kh; p->prepared.kw = pd.kw; p->prepared.stream = p->stream;
     } else if (g.fast_fwd) {
         FastColsFwdArgs fa = fast_cols_fwd_args(g, p->d, dimg, (size_t)g.H * g.W, g.H, g.H, g.W, g.F, sgen,
-                                                (size_t)g.rows * g.s_pitch, g.s_pitch);
+                                                (size_t)g.rows * g.s_pitch, g.s_pitch, false);
         HIP_TRY(launch_fast_cols_fwd(g.M, g.fast_cols.T, false, fa, p->num_cus, p->stream));
     } else {
         ColsR2CArgs ia = image_cols_args(g, p->t, p->d, dimg, sgen);
@@ -2043,6 +2052,21 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         return 0;
     }
     if (!strcmp(name, "verbose")) { plan->opt_verbose = value != 0; return 0; }
+    if (!strcmp(name, "dynamic_tiles")) {
+        // the persistent column kernels (output columns; image and kernel columns forwards) take their tiles from a queue in
+        // device memory (1, the default where the plan has specialised column kernels) instead of a fixed share per workgroup
+        // (0): see fast_cols.hpp: TileQueue.  A step that shares the GPU with another kernel -- the broadcast of a multi-GPU
+        // run, another library's work -- loses half as much with the queue; 0 is kept for A/B runs.
+        if (value && !plan->g.fast_cols.ok) value = 0;      // (generic kernels: one workgroup per tile, dealt by the hardware)
+        if (value && !plan->queue.p) {     // zeroed once: every launch leaves the counters at zero (fast_cols.hpp: queue_leave)
+            if (int rc = use_device(plan)) return rc;
+            if (int rc = plan->queue.ensure(FC_QUEUE_WORDS)) return rc;
+            HIP_TRY(hipMemset(plan->queue.p, 0, FC_QUEUE_WORDS * sizeof(int)));
+        }
+        plan->opt_dynamic_tiles = value != 0;
+        plan->d.queue = value ? plan->queue.p : nullptr;
+        return 0;
+    }
     if (!strcmp(name, "defer_prepare")) {
         if (!value && plan->deferred.on) {
             if (int rc = use_device(plan)) return rc;
@@ -2114,6 +2138,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "flip_kernels")) { *value = plan->opt_flip_kernels; return 0; }
     if (!strcmp(name, "profile")) { *value = plan->profile ? 1 : 0; return 0; }
     if (!strcmp(name, "verbose")) { *value = plan->opt_verbose; return 0; }
+    if (!strcmp(name, "dynamic_tiles")) { *value = plan->opt_dynamic_tiles; return 0; }
     if (!strcmp(name, "defer_prepare")) { *value = plan->opt_defer_prepare; return 0; }
     if (!strcmp(name, "prepare_pending")) { *value = plan->deferred.on ? 1 : 0; return 0; }   // read-only: a recorded, not yet launched preparation
     return fail(FFTCONV_ERR_INVALID_ARG, "unknown option '%s'", name);

@@ -193,6 +193,7 @@ struct DeviceTables {
     const PairEntry* fc_pairs = nullptr;
     const int* fc_rowoff = nullptr;
     const int* fc_pair_row_of = nullptr;
+    int* queue = nullptr;                     // dynamic tile queue of the persistent column kernels (FC_QUEUE_WORDS ints; plan option "dynamic_tiles")
     unsigned long long* timeline = nullptr;   // FC_ROWS_TIMELINE / FC_COLS_TIMELINE builds only (plan option "timeline_ptr")
 };
 
@@ -274,18 +275,22 @@ inline FastColsArgs fast_cols_args(const Geometry& g, const DeviceTables& d, con
     a.rowoff = d.fc_rowoff; a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
     a.y_tiled = g.y_tiled() ? 1 : 0; a.y_tile_elems = g.tile_rows() * g.y_tile_w; a.y_tile_shift = g.y_tile_shift;
     a.timeline = d.timeline;
+    a.queue = d.queue;          // counters 0..7 (one per XCD)
     return a;
 }
 
-// forward column pass of `planes` planes of `ncols` columns with h_in valid samples each
+// forward column pass of `planes` planes of `ncols` columns with h_in valid samples each; of_kernels: the kernels' pass
+// (counter 9 of the dynamic tile queue; the image's pass has counter 8 -- the two may run at the same time, on two
+// streams or in one launch)
 inline FastColsFwdArgs fast_cols_fwd_args(const Geometry& g, const DeviceTables& d, const float* in, size_t in_plane_stride,
                                           int in_col_pitch, int h_in, int ncols, int planes, c32* out,
-                                          size_t out_plane_stride, int out_pitch) {
+                                          size_t out_plane_stride, int out_pitch, bool of_kernels) {
     FastColsFwdArgs a{};
     a.in = in; a.in_plane_stride = in_plane_stride; a.in_col_pitch = in_col_pitch; a.h_in = h_in; a.ncols = ncols;
     a.out = out; a.out_plane_stride = out_plane_stride; a.out_pitch = out_pitch;
     a.tiles_per_plane = (ncols + g.fast_cols.T - 1) / g.fast_cols.T; a.ntiles = a.tiles_per_plane * planes;
     a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
+    a.queue = d.queue ? d.queue + (of_kernels ? 9 : 8) * FC_QUEUE_STRIDE : nullptr;
     return a;
 }
 

@@ -92,11 +92,17 @@ class FilterShardedConvolver:
     step k, which takes the image transform and the broadcast off the critical path of every step
     but the first.  A buffer is overwritten only after the convolve that read it (events)."""
 
-    def __init__(self, engine, dist, rank, world, n_filters, src=0, depth=2, always_collective=False, time_broadcast=None):
+    def __init__(self, engine, dist, rank, world, n_filters, src=0, depth=2, always_collective=False, time_broadcast=None,
+                 side_work=None):
         """time_broadcast: None, "wall" (host clock around the call: backends that block the host, gloo) or "event"
-        (an event pair on the side stream around it: nccl); broadcast_ms() returns what was measured."""
+        (an event pair on the side stream around it: nccl); broadcast_ms() returns what was measured.
+        side_work: callable(stream handle) queued on the side stream where the broadcast goes -- bench.py --contend puts
+        a stand-in for the collective's kernel there on a one-GPU box (tools/microbench/cu_hog)."""
         self.engine, self.dist, self.rank, self.world, self.src = engine, dist, rank, world, src
         self.time_broadcast = time_broadcast
+        self.side_work = side_work
+        # (the step shares the GPU with the collective's kernels: the plan's persistent column kernels take their tiles from
+        #  a queue -- plan option "dynamic_tiles", on by default -- so a CU the collective holds delays nobody's share)
         self._bc_wall, self._bc_events = [], []
         self.first, self.count = filter_shard(n_filters, rank, world)
         self.depth = max(1, int(depth))
@@ -144,6 +150,8 @@ class FilterShardedConvolver:
                 elif ev0 is not None:
                     ev1.record(torch.cuda.current_stream())
                     self._bc_events.append((ev0, ev1))
+            if self.side_work is not None:
+                self.side_work(self.engine.torch.cuda.current_stream().cuda_stream)
             s.record(self.ready[b], side=True)
         self.n_sub += 1
 

@@ -19,6 +19,11 @@ namespace {
 PlanTuning g_tune;   // path mode / rows group of the emulated plans (pipeline.hpp PlanTuning)
 // the output window of a block of an overlap-save block-wise plan (fftconv_api.cpp: OutWindow), applied to the output kernel
 struct { bool on = false; int h_lo = 0, h_hi = 0, w_first = 0, ncols = 0, pitch = 0; } g_win;
+// dynamic tile queue of the persistent column kernels (plan option "dynamic_tiles"): the emulated "workgroups" run one after
+// the other, so the first takes every tile of its home counter and then those of the others -- the ticket -> tile map, the
+// hand-over through the LDS slot and the termination are what this exercises
+bool g_dynamic_tiles = false;
+int g_queue[FC_QUEUE_WORDS];
 }  // namespace
 
 extern "C" {
@@ -37,6 +42,7 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
     Tables t;
     if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     DeviceTables d;
+    d.queue = g_dynamic_tiles ? g_queue : nullptr;
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
     d.pairs = t.pairs.data();
@@ -47,7 +53,7 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
     for (size_t i = 0; i < g.spectrum_elems(); i++) S[i] = mk(1e30f, -1e30f);
     if (g.fast_fwd) {
         d.fc_tw1 = t.fcl.tw1.data(); d.fc_tw2 = t.fcl.tw2.data(); d.fc_pairs = t.fcl.pairs.data();
-        FastColsFwdArgs fa = fast_cols_fwd_args(g, d, data, (size_t)H * W, H, H, W, F, S, (size_t)g.rows * g.s_pitch, g.s_pitch);
+        FastColsFwdArgs fa = fast_cols_fwd_args(g, d, data, (size_t)H * W, H, H, W, F, S, (size_t)g.rows * g.s_pitch, g.s_pitch, false);
         EmuFastColsFwd run{fa, lds.data(), 3};
         if (!run_fast_cols_fwd(g.M, g.fast_cols.T, false, run)) return -8;
     } else {
@@ -75,6 +81,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
     Tables t;
     if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     DeviceTables d;
+    d.queue = g_dynamic_tiles ? g_queue : nullptr;
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
     d.pairs = t.pairs.data();
@@ -91,7 +98,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
         if (g.fast_fwd) {
             d.fc_tw1 = t.fcl.tw1.data(); d.fc_tw2 = t.fcl.tw2.data(); d.fc_pairs = t.fcl.pairs.data();
             FastColsFwdArgs fa = fast_cols_fwd_args(g, d, kernels[k], (size_t)kh[k] * kw[k], kh[k], kh[k], kw[k], F, A.data(),
-                                                    (size_t)g.rows * a_pitch_for(kw[k]), a_pitch_for(kw[k]));
+                                                    (size_t)g.rows * a_pitch_for(kw[k]), a_pitch_for(kw[k]), true);
             EmuFastColsFwd run{fa, lds.data(), 2};
             if (!run_fast_cols_fwd(g.M, g.fast_cols.T, fast_cols_fwd_pruned_ok(g.fast_cols, kh[k]), run)) return -8;
         } else {
@@ -170,6 +177,7 @@ int emu_fft1d(int L, const float* xin /* 2L floats */, float* xout /* 2L floats 
 void emu_set_tuning(int path_mode, int rows_group) { g_tune.path_mode = path_mode; g_tune.rows_group = rows_group; }
 // 1: the emulated plans transform the ceil16 window itself (fftconv_plan_options.exact_window)
 void emu_set_exact_window(int on) { g_tune.exact_window = on != 0; }
+void emu_set_dynamic_tiles(int on) { g_dynamic_tiles = on != 0; }
 void emu_allow_fast(int mode) { g_tune.path_mode = mode; }
 // 1: the emulated plans are block plans of an overlap-save block-wise plan: H x W is the transform, the result circular
 void emu_set_cyclic(int on) { g_tune.cyclic = on != 0; }

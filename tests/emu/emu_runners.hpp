@@ -113,6 +113,9 @@ struct EmuFastCols {
         // sliced body runs on the CPU tier too (e.g. 18 tiles = 2 full rounds of 8 + 2 tiles in 4 slices each)
         const bool sliced = (Cfg::M <= FC_SLICE_MAX_M) && fast_cols_slice_plan(Cfg::M, Cfg::T, 8, b, sgrid);
         const int loops = sliced ? 8 : nwg;
+        FastColsArgs q = a;            // dynamic tile queue (unsliced launches): counters zeroed, chunks of two tiles
+        if (a.queue) q.queue_shift = 1;      // (the counters are zero between launches: the last workgroup out zeroes them)
+        b.queue = nullptr;
         for (int wg = 0; wg < loops; wg++) {
             for (int i = 0; i < Cfg::LDS_ELEMS; i++) lds[i] = mk(1e30f, -1e30f);
             if (a.y_tiled) {
@@ -123,11 +126,13 @@ struct EmuFastCols {
                         continue;
                     }
                 }
-                fast_cols_body<Cfg, true>(pctx, lds, a, wg, nwg);
+                if (q.queue) fast_cols_body<Cfg, true, false, true>(pctx, lds, q, wg, nwg);
+                else fast_cols_body<Cfg, true>(pctx, lds, q, wg, nwg);
                 continue;
             }
             HostPhaseCtx<ColState<Cfg>> ctx(Cfg::NT);
-            fast_cols_body<Cfg, false>(ctx, lds, a, wg, nwg);
+            q.queue = nullptr;         // (row-major intermediate: static deal only, as the product's launcher)
+            fast_cols_body<Cfg, false>(ctx, lds, q, wg, nwg);
         }
     }
 };

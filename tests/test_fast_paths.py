@@ -166,6 +166,48 @@ def test_emulated_multi_map_row_kernel(emu, oracle, tuned, shape):
         assert util.rel_err(g, r) < 1e-5
 
 
+# Dynamic tile queue of the persistent column kernels (fast_cols.hpp: TileQueue; plan option "dynamic_tiles"): the same bodies
+# taking their tiles from the queue's counters instead of the static deal.  Emulated workgroups run one after the other, so
+# the first drains its home counter and then the other seven (the stealing pass): the ticket -> tile map, the hand-over of
+# the tile after next through the LDS slot and the termination are what is checked here; contention is a GPU matter.
+DYN_SHAPES = [(256, 256, 1, 31, 31, 2), (1024, 1024, 1, 63, 63, 1), (2048, 300, 2, 63, 20, 1), (4096, 24, 1, 127, 9, 2),
+              (4200, 10, 2, 25, 7, 1), (6000, 250, 1, 60, 31, 1), (340, 350, 1, 31, 31, 2), (20, 4096, 1, 5, 127, 2)]
+
+
+@pytest.mark.parametrize("shape", DYN_SHAPES)
+def test_emulated_dynamic_tile_queue(emu, oracle, shape):
+    H, W, F, kh, kw, n = shape
+    data, ks = make_inputs(shape, 71)
+    emu.emu_set_dynamic_tiles(1)
+    try:
+        rc, got = emu_conv(emu, data, kh, kw, ks)
+    finally:
+        emu.emu_set_dynamic_tiles(0)
+    assert rc == 0
+    for g, r in zip(got, oracle.conv_fft(data, kh, kw, ks)):
+        assert util.rel_err(g, r) < 1e-5
+
+
+def test_dynamic_tile_queue_ticket_map_is_a_bijection():
+    """ticket k of XCD v -> tile ((k >> s) * 8 + v) << s | (k & mask): every tile below n exactly once over the eight counters,
+    ascending in k per counter (so a counter that has run out stays run out), chunks of 2^s consecutive tiles per XCD in turn"""
+    def tile(v, k, s):
+        return ((((k >> s) << 3) + v) << s) + (k & ((1 << s) - 1))
+    for s in (0, 1, 3, 5):
+        for n in (1, 7, 8, 33, 528, 1000):
+            seen = []
+            for v in range(8):
+                prev = -1
+                for k in range(n + 64):
+                    t = tile(v, k, s)
+                    assert t > prev
+                    prev = t
+                    if t < n:
+                        seen.append(t)
+                        assert (t >> s) % 8 == v
+            assert sorted(seen) == list(range(n))
+
+
 # the BASELINE windows that are awkward to factor have kernels of their own (1088 = 2^6 x 17: cfg2; 4160 = 2^6 x 5 x 13:
 # cfg4); plans that must transform the window itself (exact_window: the spectrum exchange in the reference's order,
 # src/cudaFFTData.cu:90-103, src/cudaConvFFTData.cu:92-98) run on them

@@ -390,6 +390,73 @@ def test_cfg3_headline_launch_geometry(fc, oracle):
         assert util.rel_err(out[j].cpu().numpy().T, r) < TOL
 
 
+def _device_run_opts(fc, torch, img, ks_packed, kh, kw, opts):
+    dev = torch.device("cuda", 0)
+    F, W, H = img.shape
+    n = ks_packed.shape[0]
+    with fc.Plan(H, W, F, kh, kw) as p:
+        for k, v in opts.items():
+            p.set_option(k, v)
+            assert p.get_option(k) == v
+        out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+        if opts.get("defer_prepare"):        # kernels' columns ride in the image's column launch (k_fast_cols_fwd_pair)
+            p.prepare_kernels_packed_device(n, ks_packed.data_ptr(), kh, kw)
+        p.set_image_device(img.data_ptr())
+        p.convolve_packed_device(n, ks_packed.data_ptr(), kh, kw, out.data_ptr())
+        p.synchronize()
+    return out
+
+
+# (H, W, F, K, n): cfg4's share geometry (window 4160 cropped from 4224, a full launch + a partial one), cfg3's, cfg5's (2112),
+# 4-column output tiles (M = 3072), a small transform whose launch would be sliced (static fall-back inside the dynamic
+# plan), F > 1, and a launch of fewer tiles than workgroups
+DYNAMIC_TILE_SHAPES = [(4096, 4096, 1, 63, 70), (4096, 4096, 1, 127, 9), (2048, 2048, 1, 63, 33), (6000, 700, 1, 63, 5),
+                       (1024, 1024, 1, 63, 16), (1500, 1400, 3, 31, 7), (256, 256, 1, 31, 1)]
+
+
+@pytest.mark.parametrize("shape", DYNAMIC_TILE_SHAPES)
+@pytest.mark.parametrize("defer", [0, 1])
+def test_dynamic_tile_queue_matches_static_deal(fc, oracle, shape, defer):
+    """Plan option "dynamic_tiles" (fast_cols.hpp: TileQueue; the default): the persistent column kernels take their tiles from a
+    queue in device memory -- robust where a step shares the GPU with a collective (src/cudaConvFFTDataStreams.cu:279-289,338-447).
+    A tile is computed by the same code whoever takes it, so the maps must equal the static deal's BIT FOR BIT; the first
+    and the last map also go against the oracle.  defer = 1: the image's and the kernels' column passes in one launch."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H, W, F, K, n = shape
+    g = torch.Generator(device="cpu").manual_seed(77 + H + n)
+    img = torch.rand((F, W, H), generator=g, dtype=torch.float32)
+    ks = torch.rand((n, F, K, K), generator=g, dtype=torch.float32)
+    base = {"defer_prepare": 1} if defer else {}
+    ref_out = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=0))
+    dyn_out = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=1))
+    assert torch.equal(ref_out, dyn_out)
+    again = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=1))   # counters zeroed per launch
+    assert torch.equal(dyn_out, again)
+    if H * W <= 2048 * 2048 or not defer:
+        idx = sorted({0, n - 1})
+        img_np = np.asfortranarray(np.transpose(img.numpy(), (2, 1, 0)))
+        k_np = [np.asfortranarray(np.transpose(ks[j].numpy(), (2, 1, 0))) for j in idx]
+        for j, r in zip(idx, oracle.conv_fft(img_np, K, K, k_np)):
+            assert util.rel_err(dyn_out[j].cpu().numpy().T, r) < TOL
+
+
+def test_dynamic_tile_queue_host_entries(fc, oracle):
+    """the queue behind the host-array entries (plan convolve with pointer arrays, host output) and across a change of the option"""
+    rng = np.random.default_rng(5)
+    img = rng.random((1800, 1700, 1), dtype=np.float32)
+    ks = [rng.random((40, 50, 1), dtype=np.float32) for _ in range(5)] + [rng.random((17, 9, 1), dtype=np.float32)]
+    ref = oracle.conv_fft(img, 40, 50, ks)
+    with fc.Plan(1800, 1700, 1, 40, 50) as p:
+        p.set_image(img)
+        for dyn in (1, 0, 1):
+            p.set_option("dynamic_tiles", dyn)
+            if dyn:
+                p.set_image(img)                 # the image's column pass through the queue too
+            for g, r in zip(p.convolve(ks), ref):
+                assert util.rel_err(g, r) < TOL
+
+
 def test_cfg4_headline_launch_geometry(fc, oracle):
     """The launch geometry bench.py times for BASELINE configs[3] (one rank's share, and the 1-GPU denominator):
     4096x4096 image, 63x63 kernels, 84 kernels in one packed call = a full 64-map launch of the multi-map row
