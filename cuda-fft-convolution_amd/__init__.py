@@ -1,6 +1,6 @@
 """Python binding of libfftconv.so, the MI355X-native 2-D FFT-convolution engine.
 
-The host side of the product is C++ (``csrc/fftconv_api.cpp``, the role of the reference's MEX
+The host side of the product is C++ (``csrc/fftconv_api.cpp`` and the units beside it (``csrc/plan_internal.hpp`` lists them), the role of the reference's MEX
 gateways); this module is only the ctypes stub over the C ABI of ``include/fftconv.h`` plus a
 mirror of the reference's MATLAB call surface so tests read like the reference's demo:
 

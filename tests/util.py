@@ -21,13 +21,13 @@ def ceil16(n):
     return (n + 15) // 16 * 16
 
 
-def _build(path, target_dir):
+def _build(path, target_dir, target=None):
     """make -C target_dir, one process at a time (pytest-xdist workers would otherwise run the same make side by side)"""
     import fcntl
     with open(os.path.join(target_dir, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            subprocess.run(["make", "-C", target_dir], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            subprocess.run(["make", "-C", target_dir] + ([target] if target else []), check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     assert os.path.exists(path), path
@@ -44,11 +44,13 @@ class Oracle:
     """ctypes view of oracle/liboracle.so -- the CPU restatement of the reference path.
     Used by tests / smoke / the bench's cpu_baseline leg only."""
 
-    def __init__(self):
+    def __init__(self, native=False):
+        """native=True: the same source built -march=native for THIS host (oracle/_native/, made on the spot; the bench's
+        cpu_baseline leg only -- the tests check against the portable build)."""
         d = os.path.join(ROOT, "oracle")
-        so = os.path.join(d, "liboracle.so")
-        if not os.path.exists(so):
-            _build(so, d)
+        so = os.path.join(d, "_native", "liboracle.so") if native else os.path.join(d, "liboracle.so")
+        if native or not os.path.exists(so):
+            _build(so, d, "native" if native else None)
         self.lib = ctypes.CDLL(so)
         self.lib.oracle_num_threads.argtypes = [ctypes.c_int]
 
@@ -102,11 +104,11 @@ class CpuF32:
     """ctypes view of oracle/libcpu_f32.so: the fp32 half-spectrum CPU restatement (second CPU
     baseline of SURVEY.md 8(d)); same contract as Oracle.conv_fft."""
 
-    def __init__(self):
+    def __init__(self, native=False):
         d = os.path.join(ROOT, "oracle")
-        so = os.path.join(d, "libcpu_f32.so")
-        if not os.path.exists(so):
-            _build(so, d)
+        so = os.path.join(d, "_native", "libcpu_f32.so") if native else os.path.join(d, "libcpu_f32.so")
+        if native or not os.path.exists(so):
+            _build(so, d, "native" if native else None)
         self.lib = ctypes.CDLL(so)
 
     def conv_fft(self, data, mkh, mkw, kernels, threads=0):

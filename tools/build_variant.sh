@@ -13,8 +13,9 @@ for src in $SRC/kernels*.hip; do      # kernels.hip + one translation unit per k
   f=$(basename $src .hip)
   /opt/rocm/bin/hipcc $FLAGS -I$SRC -c $src -o $OBJ/$f.o & pids="$pids $!"
 done
-/opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_api.cpp -o $OBJ/fftconv_api.o & pids="$pids $!"
-/opt/rocm/bin/hipcc $FLAGS -c $SRC/fftconv_multi.cpp -o $OBJ/fftconv_multi.o & pids="$pids $!"
+for f in fftconv_api plan_cache host_ring blockwise placement fftconv_multi; do      # the host units (csrc/Makefile: HOSTUNITS)
+  /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.cpp -o $OBJ/$f.o & pids="$pids $!"
+done
 for p in $pids; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/cuda-fft-convolution_amd/ab/$NAME.so $OBJ/*.o -ldl
 echo built cuda-fft-convolution_amd/ab/$NAME.so
