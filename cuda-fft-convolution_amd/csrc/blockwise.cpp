@@ -171,7 +171,7 @@ int tiled_set_image(fftconv_plan* p, const float* data, int location) {
                 for (int f = 0; f < F && any; f++)
                     for (int x = xs; x < xe; x++)
                         memcpy(&ts->hblk[((size_t)f * Lw + (x - x0)) * Lh + (ys - y0)], &data[((size_t)f * W + x) * H + ys], (size_t)(ye - ys) * sizeof(float));
-                if (int rc = fftconv_plan_set_image(sub, ts->hblk.data(), FFTCONV_HOST)) return rc;   // synchronous for host input
+                if (int rc = fftconv_plan_set_image(sub, ts->hblk.data(), FFTCONV_HOST)) return rc;   // (hblk is consumed on return: copied or staged)
             } else {
                 HIP_TRY(hipMemsetAsync(ts->blk.p, 0, (size_t)Lh * Lw * F * sizeof(float), sub->stream));
                 for (int f = 0; f < F && any; f++)
@@ -195,7 +195,7 @@ int tiled_set_image(fftconv_plan* p, const float* data, int location) {
             for (int f = 0; f < F; f++)
                 for (int x = 0; x < wv; x++)
                     memcpy(&ts->hblk[((size_t)f * Bw + x) * Bh], &data[((size_t)f * W + (x0 + x)) * H + y0], (size_t)hv * sizeof(float));
-            if (int rc = fftconv_plan_set_image(sub, ts->hblk.data(), FFTCONV_HOST)) return rc;   // synchronous for host input
+            if (int rc = fftconv_plan_set_image(sub, ts->hblk.data(), FFTCONV_HOST)) return rc;   // (hblk is consumed on return: copied or staged)
         } else {
             // the block, zero-padded, on the device: one strided copy per feature plane (h is contiguous)
             if (hv < Bh || wv < Bw) HIP_TRY(hipMemsetAsync(ts->blk.p, 0, (size_t)Bh * Bw * F * sizeof(float), sub->stream));
@@ -210,6 +210,30 @@ int tiled_set_image(fftconv_plan* p, const float* data, int location) {
     return 0;
 }
 
+// The finished full-window maps of a chunk of kernels (`big`, nk maps from kernel k0 on) on their way to the caller: cropped to
+// the plan's "output_region" where one is set, then copied to the caller's pointers -- or nothing at all where the blocks
+// stored straight into the caller's packed maps.  more: another chunk follows and reuses `big`.
+static int tiled_deliver(fftconv_plan* p, float* big, int nk, int k0, bool more, float* const* out, int out_location, float* out_packed) {
+    TiledState* ts = p->tiled;
+    fftconv_plan* sub = ts->sub;
+    const size_t big_map = ts->big_map(), oe = p->out_elems();
+    const float* src = big;
+    if (p->opt_region != 0) {
+        float* dst = out_packed ? out_packed + (size_t)k0 * oe : ts->crop.p;
+        if (p->opt_region == 4) HIP_TRY(launch_pad_maps(big, ts->FH, ts->FW, big_map, dst, p->out_h, p->out_w, oe, nk, sub->stream));
+        else HIP_TRY(launch_crop_maps(big, ts->FH, big_map, dst, p->out_h, p->out_w, oe, p->off_h, p->off_w, nk, sub->stream));
+        src = dst;
+    } else if (out_packed) {
+        return 0;
+    }
+    if (!out_packed)
+        for (int j = 0; j < nk; j++)
+            HIP_TRY(hipMemcpyAsync(out[k0 + j], src + (size_t)j * oe, oe * sizeof(float),
+                                   out_location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sub->stream));
+    if ((!out_packed && out_location == FFTCONV_HOST) || more) HIP_TRY(hipStreamSynchronize(sub->stream));   // `big` (and the crop staging) are reused by the next chunk
+    return 0;
+}
+
 // Overlap-save: every block's run stores its rectangle of the maps from the output kernel (OutWindow) -- no block maps, no
 // summing pass, every element of the maps written once.  Kernels of equal size go through the block plan group by group
 // (run_group); host kernels, and device kernels that are not consecutive in memory, are packed on the device once per call.
@@ -219,14 +243,21 @@ int tiled_convolve_save(fftconv_plan* p, int n, const float* const* kernels, con
     fftconv_plan* sub = ts->sub;
     const size_t big_map = ts->big_map();
     const size_t budget = (size_t)6 << 30;
-    const int nc = out_packed ? n : (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / (big_map * sizeof(float))));
-    if (!out_packed)
+    // "output_region" other than the window: the blocks still store into full-window maps (the output kernel's stores are
+    // pairs of rows at even offsets: an arbitrary rectangle is not), a crop kernel compacts the region out of them
+    const bool cropped = p->opt_region != 0;
+    const size_t oe = p->out_elems();
+    const bool direct = out_packed && !cropped;       // the blocks store straight into the caller's packed maps
+    const int nc = direct ? n : (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / (big_map * sizeof(float))));
+    if (!direct)
         if (int rc = ts->big.ensure(big_map * nc)) return rc;
+    if (cropped && !out_packed)
+        if (int rc = ts->crop.ensure(oe * nc)) return rc;
     FC_VERBOSE(p, "N Kernel: %d (block-wise, overlap-save: %d blocks, %d kernels per chunk)", n, ts->nblk, nc);
     struct Group { int first, count; const float* dk; };
     for (int k0 = 0; k0 < n; k0 += nc) {
         const int nk = std::min(nc, n - k0);
-        float* big = out_packed ? out_packed + (size_t)k0 * big_map : ts->big.p;
+        float* big = direct ? out_packed + (size_t)k0 * big_map : ts->big.p;
         // groups of consecutive kernels of equal size, each packed on the device
         std::vector<Group> groups;
         size_t stage_total = 0;
@@ -279,12 +310,7 @@ int tiled_convolve_save(fftconv_plan* p, int n, const float* const* kernels, con
                 if (rc) return rc;
             }
         }
-        if (!out_packed) {
-            for (int j = 0; j < nk; j++)
-                HIP_TRY(hipMemcpyAsync(out[k0 + j], big + (size_t)j * big_map, big_map * sizeof(float),
-                                       out_location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sub->stream));
-            if (out_location == FFTCONV_HOST || k0 + nc < n) HIP_TRY(hipStreamSynchronize(sub->stream));   // `big` is reused by the next chunk
-        }
+        if (int rc = tiled_deliver(p, big, nk, k0, k0 + nc < n, out, out_location, out_packed)) return rc;
         if (stage_total && k0 + nc < n) HIP_TRY(hipStreamSynchronize(sub->stream));                       // ... and so is the kernel staging
     }
     FC_VERBOSE(p, "FFT done");
@@ -311,15 +337,19 @@ int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const in
     const size_t big_map = ts->big_map(), blk_map = sub->g.map_elems();
     const size_t budget = (size_t)6 << 30;
     const int nc = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, budget / ((big_map + blk_map) * sizeof(float))));
-    if (!out_packed)
+    const bool cropped = p->opt_region != 0;          // as in tiled_convolve_save: full-window maps first, the region cropped out of them
+    const bool direct = out_packed && !cropped;
+    if (!direct)
         if (int rc = ts->big.ensure(big_map * nc)) return rc;
+    if (cropped && !out_packed)
+        if (int rc = ts->crop.ensure(p->out_elems() * nc)) return rc;
     if (int rc = ts->tmp.ensure(blk_map * nc)) return rc;
     std::vector<float*> tptr(nc);
     for (int j = 0; j < nc; j++) tptr[j] = ts->tmp.p + (size_t)j * blk_map;
     FC_VERBOSE(p, "N Kernel: %d (block-wise: %d blocks, %d kernels per chunk)", n, ts->nblk, nc);
     for (int k0 = 0; k0 < n; k0 += nc) {
         const int nk = std::min(nc, n - k0);
-        float* big = out_packed ? out_packed + (size_t)k0 * big_map : ts->big.p;
+        float* big = direct ? out_packed + (size_t)k0 * big_map : ts->big.p;
         // host (or mixed) kernels: on the device once per chunk, not once per block (every block convolves the same kernels)
         const float* const* kptr = kernels + k0;
         int kloc = kernel_location;
@@ -349,13 +379,7 @@ int tiled_convolve(fftconv_plan* p, int n, const float* const* kernels, const in
             hipError_t e = launch_add_window(big, ts->FH, ts->FW, big_map, y0, x0, ts->tmp.p, sub->g.fft_h, sub->g.fft_w, blk_map, nk, sub->stream);
             if (e != hipSuccess) return api_fail(FFTCONV_ERR_HIP, "overlap-add failed: %s", hipGetErrorString(e));
         }
-        if (!out_packed) {
-            for (int j = 0; j < nk; j++) {
-                HIP_TRY(hipMemcpyAsync(out[k0 + j], big + (size_t)j * big_map, big_map * sizeof(float),
-                                       out_location == FFTCONV_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, sub->stream));
-            }
-            if (out_location == FFTCONV_HOST || k0 + nc < n) HIP_TRY(hipStreamSynchronize(sub->stream));   // `big` is reused by the next chunk
-        }
+        if (int rc = tiled_deliver(p, big, nk, k0, k0 + nc < n, out, out_location, out_packed)) return rc;
     }
     FC_VERBOSE(p, "FFT done");
     return 0;

@@ -207,7 +207,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
                 HIP_TRY(launch_fast_rows_multi(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_group_for(ny, p->num_cus), p->stream));
             } else if (g.fast_rows.ok) {
                 FastRowsArgs fa = fast_rows_args(g, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
-                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, g.rows_wg_order, p->stream));
+                HIP_TRY(launch_fast_rows(g.Lw, fast_rows_nz2(g, kw), fa, g.rows, ny, p->stream));
             } else {
                 SpectralRowsArgs sa = spectral_rows_args(g, p->t, p->d, p->A.p + (size_t)y0 * per_a, kw, p->spec(), p->Y.p);
                 HIP_TRY(launch_spectral_rows(sa, g.rows, ny, rthreads, p->rows_lds(), p->stream));
@@ -517,11 +517,10 @@ int fftconv_plan_get_info(const fftconv_plan* plan, fftconv_plan_info* info) {
     info->workspace_bytes = plan->A.bytes() + plan->Y.bytes() + plan->K.bytes() + plan->O.bytes() + plan->I.bytes();
     if (const TiledState* ts = plan->tiled) {     // block-wise: the window of the whole image; the spectrum is every block's
         info->spectrum_bytes = ts->spec_total() * sizeof(c32);
-        info->map_bytes = info->out_map_bytes = ts->big_map() * sizeof(float);
-        info->out_h = ts->FH; info->out_w = ts->FW;
+        info->map_bytes = ts->big_map() * sizeof(float);
         fftconv_plan_info si;
         if (fftconv_plan_get_info(ts->sub, &si) == 0)
-            info->workspace_bytes = si.workspace_bytes + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes() + (ts->specs_x ? 0 : ts->specs.bytes());
+            info->workspace_bytes = si.workspace_bytes + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes() + ts->crop.bytes() + (ts->specs_x ? 0 : ts->specs.bytes());
     }
     return 0;
 }
@@ -776,6 +775,8 @@ int fftconv_plan_convolve(fftconv_plan* plan, int n_kernel, const float* const* 
             if (int rc = p->pin_k.wait()) return rc;
             for (int j = 0; j < n; j++) memcpy(p->pin_k.p + per * j * sizeof(float), kernels[k0 + j], per * sizeof(float));
             dk = reinterpret_cast<const float*>(p->pin_k.p);
+            if (p->prepared.dk == dk) p->prepared.dk = nullptr;      // column spectra of the buffer's previous contents
+            if (p->deferred.on && p->deferred.dk == dk) p->deferred.on = false;
         } else {
             if (int rc = p->K.ensure(per * n)) return rc;
             for (int j = 0; j < n; j++)
@@ -829,8 +830,7 @@ int fftconv_plan_synchronize(fftconv_plan* plan) {
 
 int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     if (!plan || !name) return api_fail(FFTCONV_ERR_INVALID_ARG, "NULL argument");
-    if (plan->tiled) {      // block-wise: options act on the block plan; the window options have no block-wise form
-        if (!strcmp(name, "output_region") && value != 0) return tiled_unsupported("output_region");
+    if (plan->tiled && strcmp(name, "output_region")) {      // block-wise: options act on the block plan ("output_region": on this one, below)
         if (!strcmp(name, "verbose")) plan->opt_verbose = value != 0;
         return fftconv_plan_set_option(plan->tiled->sub, name, value);
     }
@@ -887,6 +887,8 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         if (int rc = use_device(plan)) return rc;
         HIP_TRY(hipStreamSynchronize(plan->stream));
         plan->release_ring();          // sized for the map bytes
+        // (block-wise plans: g is the whole image's geometry; the blocks keep storing full-window maps and the region is cropped
+        //  out of them on delivery, blockwise.cpp: tiled_deliver)
         plan->opt_region = value; plan->out_h = oh; plan->out_w = ow; plan->off_h = fh; plan->off_w = fw;
         return 0;
     }
@@ -914,7 +916,7 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!plan || !name || !value) return api_fail(FFTCONV_ERR_INVALID_ARG, "null argument");
     if (!strcmp(name, "blockwise")) { *value = plan->tiled ? plan->tiled->nblk : 0; return 0; }   // read-only: number of blocks (0 = one pass)
     if (!strcmp(name, "overlap_save")) { *value = plan->tiled && plan->tiled->save ? 1 : 0; return 0; }   // read-only: blocks stored by the output kernel (1) or summed (0)
-    if (plan->tiled) return fftconv_plan_get_option(plan->tiled->sub, name, value);
+    if (plan->tiled && strcmp(name, "output_region")) return fftconv_plan_get_option(plan->tiled->sub, name, value);
     if (!strcmp(name, "batch_maps")) { *value = plan->opt_batch_maps; return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { *value = plan->opt_kernel_chunk_mb; return 0; }
     if (!strcmp(name, "tune_placement")) { *value = plan->opt_tune_placement; return 0; }

@@ -144,7 +144,7 @@ hipError_t launch_crop_maps(const float* src, int src_h, size_t src_map_stride, 
 #define FC_DECL_GROUP(G)                                                                                                              \
     hipError_t launch_fast_rows_fwd_g##G(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s, bool* matched);                   \
     hipError_t launch_fast_rows_multi_g##G(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s, bool* matched); \
-    hipError_t fast_rows_multi_wgs_per_cu_g##G(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu);
+    hipError_t fast_rows_multi_wgs_per_cu_g##G(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu, bool* matched);
 FC_DECL_GROUP(0) FC_DECL_GROUP(1) FC_DECL_GROUP(2)
 #undef FC_DECL_GROUP
 #define FC_DECL_GROUP(G)                                                                                                              \
@@ -168,7 +168,7 @@ hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipSt
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s);
 
 // one map per workgroup: the multi-map walk with a walk length of 1 (round 4: the separate one-map kernel is gone)
-hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int /*order*/, hipStream_t s) {
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, hipStream_t s) {
     return launch_fast_rows_multi(L, nz2, a, rows, kernels, 1, s);
 }
 
@@ -183,9 +183,10 @@ hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int row
 }
 
 hipError_t fast_rows_multi_wgs_per_cu(int L, int nz2, const FastRowsArgs& a, int* wgs_per_cu) {
-    hipError_t e = fast_rows_multi_wgs_per_cu_g0(L, nz2, a, wgs_per_cu);
-    if (e == hipErrorInvalidValue) e = fast_rows_multi_wgs_per_cu_g1(L, nz2, a, wgs_per_cu);
-    if (e == hipErrorInvalidValue) e = fast_rows_multi_wgs_per_cu_g2(L, nz2, a, wgs_per_cu);
+    bool m = false;
+    hipError_t e = fast_rows_multi_wgs_per_cu_g0(L, nz2, a, wgs_per_cu, &m);
+    if (!m) e = fast_rows_multi_wgs_per_cu_g1(L, nz2, a, wgs_per_cu, &m);
+    if (!m) e = fast_rows_multi_wgs_per_cu_g2(L, nz2, a, wgs_per_cu, &m);
     return e;
 }
 

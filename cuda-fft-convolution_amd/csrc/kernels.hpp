@@ -30,7 +30,7 @@ hipError_t launch_rows_fwd(const RowsFwdArgs& a, int rows, int threads, size_t l
 hipError_t launch_fast_rows_fwd(int L, const FastRowsFwdArgs& a, int rows, hipStream_t s);
 hipError_t launch_spectral_rows(const SpectralRowsArgs& a, int rows, int kernels, int threads, size_t lds_bytes, hipStream_t s);
 // fast path (fast_rows.hpp); hipErrorInvalidValue if no instantiation matches (L, nz2)
-hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int order, hipStream_t s);
+hipError_t launch_fast_rows(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, hipStream_t s);
 // several maps per workgroup (fast_rows_multi.hpp, F = 1): kernels_per_wg consecutive kernels share one fetch of the image-spectrum row
 hipError_t launch_fast_rows_multi(int L, int nz2, const FastRowsArgs& a, int rows, int kernels, int kernels_per_wg, hipStream_t s);
 // how many workgroups of that kernel a CU holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor)

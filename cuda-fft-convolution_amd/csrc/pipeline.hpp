@@ -63,7 +63,6 @@ struct Geometry {
     static constexpr int y_tile_shift = FC_Y_TILE_SHIFT;
     bool y_tiled() const { return path_mode == 2 && fast_rows.ok && fast_cols.ok && y_tile_w % fast_cols.T == 0 && fft_w % y_tile_w == 0; }
     int tile_rows() const { return y_tiled() ? M + 2 : rows; }
-    int rows_wg_order = 0;     // workgroup order of the one-map row kernel (kernels_rows.hip: k_fast_rows); 2 for F > 1
     int rows_group = -1;       // PlanTuning::rows_group
     bool rows_multi_ok() const { return rows_group != 0 && rows_group != 1 && fast_rows.ok; }
     // As many maps per workgroup as leaves >= 4 workgroups per resident slot (4 per CU), at most 16:
@@ -123,10 +122,8 @@ inline bool make_geometry(Geometry& g, Tables& t, int H, int W, int F, int max_k
     g.rows_group = tune.rows_group;
     if (H < 1 || W < 1 || F < 1 || max_kh < 1 || max_kw < 1) return false;
     g.H = H; g.W = W; g.F = F; g.max_kh = max_kh; g.max_kw = max_kw;
-    // F > 1 (plain row kernel, one map per workgroup): every (map, feature) re-reads an image-spectrum
-    // row, F times the traffic of F = 1; the XCD-aware order with the kernel index fastest lets the
-    // workgroups of one row take it from their XCD's L2 (cfg3 with F = 4: 92 -> 79 us per map)
-    g.rows_wg_order = F > 1 ? 2 : 0;
+    // (F > 1: the XCD-aware workgroup order -- the workgroups that read the same F image-spectrum rows side by side on one L2 --
+    //  lives in the walk kernel itself: kernels_rows_multi.inc: k_fast_rows_multi_f)
     g.fft_h = tune.cyclic ? H : fft_size16(H + max_kh - 1);
     g.fft_w = tune.cyclic ? W : fft_size16(W + max_kw - 1);
     if (tune.cyclic && (!allow_fast || (H & 1) || max_kh > H || max_kw > W)) return false;

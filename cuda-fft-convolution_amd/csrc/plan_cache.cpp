@@ -32,7 +32,9 @@ struct PlanCache {
     std::mutex m;
     std::vector<CacheEntry> idle;     // plans no call is using (a plan in use is simply not in here)
     int max_plans = 4;
-    size_t max_bytes = (size_t)48 << 30;
+    // device scratch of the idle plans together: a quarter of the device's memory, at most 48 GiB (set at the first put: needs
+    // the device); 0 = not yet known.  Whatever the limit, idle plans are released when an allocation fails (cache_release_idle).
+    size_t max_bytes = 0;
     unsigned long clock = 0;
     long hits = 0, misses = 0;
 };
@@ -55,7 +57,7 @@ size_t plan_device_bytes(const fftconv_plan* p) {
     size_t b = p->tw_m.bytes() + p->tw_w.bytes() + p->pairs.bytes() + p->S.bytes() + p->A.bytes() + p->Y.bytes() + p->K.bytes() + p->KF.bytes() +
                p->O.bytes() + p->OC.bytes() + p->I.bytes() + p->NS.bytes();
     if (const TiledState* ts = p->tiled) {
-        b += ts->specs.bytes() + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes() + ts->kstage.bytes();
+        b += ts->specs.bytes() + ts->big.bytes() + ts->tmp.bytes() + ts->blk.bytes() + ts->kstage.bytes() + ts->crop.bytes();
         if (ts->sub) b += plan_device_bytes(ts->sub);
     }
     return b;
@@ -84,6 +86,11 @@ void cache_put(const CacheKey& key, fftconv_plan* p) {
         std::lock_guard<std::mutex> lk(c.m);
         if (c.max_plans <= 0) drop.push_back(p);
         else {
+            if (c.max_bytes == 0) {
+                size_t free_b = 0, total_b = 0;
+                if (hipSetDevice(p->gpu_id) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+                c.max_bytes = total_b ? std::min<size_t>((size_t)48 << 30, total_b / 4) : (size_t)48 << 30;
+            }
             c.idle.push_back(CacheEntry{key, p, ++c.clock, plan_device_bytes(p)});
             auto total = [&] { size_t t = 0; for (const CacheEntry& e : c.idle) t += e.bytes; return t; };
             while (!c.idle.empty() && ((int)c.idle.size() > c.max_plans || (c.idle.size() > 1 && total() > c.max_bytes))) {
@@ -97,6 +104,27 @@ void cache_put(const CacheKey& key, fftconv_plan* p) {
     }
     for (fftconv_plan* d : drop) fftconv_plan_destroy(d);
 }
+
+}  // namespace
+
+bool fc::cache_release_idle() {
+    std::vector<CacheEntry> drop;
+    {
+        PlanCache& c = plan_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        drop.swap(c.idle);
+    }
+    if (drop.empty()) return false;
+    const std::string keep = api_last_error();
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+    for (CacheEntry& e : drop) (void)fftconv_plan_destroy(e.plan);     // (makes the plan's device current)
+    if (dev >= 0) (void)hipSetDevice(dev);
+    api_set_last_error(keep);
+    return true;
+}
+
+namespace {
 
 thread_local fftconv_call_timing g_call_timing = {0, 0, 0, 0, 0, 0};
 double ms_since(const std::chrono::steady_clock::time_point& t0) {
@@ -250,6 +278,7 @@ int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int fe
     // allocation failure the plan is not trusted again
     const bool reusable = rc == 0 || rc == FFTCONV_ERR_INVALID_ARG || rc == FFTCONV_ERR_KERNEL_SHAPE || rc == FFTCONV_ERR_KERNEL_EXCEEDS_MAX ||
                           rc == FFTCONV_ERR_THREAD_SIZE;
+    if (!p->tiled) { p->prepared.dk = nullptr; p->deferred.on = false; }   // (both may name pin_k, whose contents the next call replaces)
     if (reusable) cache_put(key, p);
     else fftconv_plan_destroy(p);
     if (rc) api_set_last_error(keep);

@@ -52,6 +52,10 @@ inline PlanTuning tuning_from(const fftconv_plan_options* o) {
     return t;
 }
 
+// plan_cache.cpp: destroys every idle plan of the one-shot entries' cache (device scratch, pinned staging, copy threads);
+// true if there was one.  Called by DevBuf::ensure when the device is out of memory.
+bool cache_release_idle();
+
 enum { PK_KERNEL_COLS = 0, PK_SPECTRAL = 1, PK_OUT_COLS = 2, PK_IMAGE_COLS = 3, PK_IMAGE_ROWS = 4, PK_COUNT = 5 };
 
 struct EventPair {
@@ -72,8 +76,15 @@ struct DevBuf {
         cap = 0;
         fresh = true;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e != hipSuccess && cache_release_idle()) {
+            // out of device memory while the one-shot entries' plan cache holds idle plans (up to 48 GiB of scratch): they go
+            // first -- the reference's contract is "all device memory is released" between calls -- and the request is repeated
+            (void)hipGetLastError();
+            e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        }
         if (e != hipSuccess) {
             p = nullptr;
+            (void)hipGetLastError();
             return api_fail(FFTCONV_ERR_ALLOC, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
         }
         cap = n;
@@ -183,7 +194,7 @@ struct fftconv_plan {
     long opt_region = 0;
     int out_h = 0, out_w = 0, off_h = 0, off_w = 0;
     DevBuf<float> OC;  // cropped maps staged for the copy-out
-    size_t out_elems() const { return opt_region ? (size_t)out_h * out_w : g.map_elems(); }
+    size_t out_elems() const { return opt_region ? (size_t)out_h * out_w : g.map_elems(); }   // (block-wise plans: g holds the whole window)
     DevBuf<float> O;   // output staging (pointer-array / host output)
     DevBuf<float> I;   // image staging (host input)
     PinBuf pin_img, pin_k, pin_out;   // pinned host staging of small host arrays (PinBuf above)
@@ -349,6 +360,7 @@ struct TiledState {
     DevBuf<c32> specs;               // block spectra, [block][spec_elems] (own buffer)
     c32* specs_x = nullptr;          // caller-owned instead (fftconv_plan_use_spectrum_buffer)
     DevBuf<float> big, tmp, blk;     // full maps of a kernel chunk, block maps of that chunk, one zero-padded image block
+    DevBuf<float> crop;              // "output_region" maps of a kernel chunk, cropped out of `big` for the copy-out
     DevBuf<float> kstage;            // host kernels of a chunk, staged on the device once (every block convolves them)
     std::vector<float> hblk;         // host staging of one image block
     bool have_image = false;
@@ -358,6 +370,6 @@ struct TiledState {
     void release() {
         if (sub) fftconv_plan_destroy(sub);
         sub = nullptr;
-        specs.release(); big.release(); tmp.release(); blk.release(); kstage.release();
+        specs.release(); big.release(); tmp.release(); blk.release(); kstage.release(); crop.release();
     }
 };

@@ -126,8 +126,11 @@ int fftconv_convolution_fft_ex(const float *data, int data_h, int data_w, int fe
  * A plan is handed to one call at a time; a concurrent call with the same key builds a plan of its own.
  * A call that fails with a HIP / allocation error does not return its plan to the cache.
  *   fftconv_cache_configure  max_plans: plans kept (default 4; 0 switches the cache off and empties it),
- *                            max_bytes: device memory the idle cached plans may hold together (default 48 GiB,
- *                            0 = keep the current value); least recently used plans go first
+ *                            max_bytes: device memory the idle cached plans may hold together (default: a quarter of
+ *                            the device's memory, at most 48 GiB; 0 = keep the current value); least recently used plans go
+ *                            first.  Whatever the limits, EVERY idle plan is released -- and the request repeated once -- when
+ *                            a device allocation of this library fails (any entry, not only the one-shot ones): cached
+ *                            scratch never turns a call that used to fit into an out-of-memory error
  *   fftconv_cache_clear      destroys every idle cached plan (device memory, host threads).  The gateways
  *                            register it with mexAtExit; a process that unloads the library calls it first.
  *   fftconv_cache_stats      nullable outputs: plans held now, hits / misses so far, device bytes held
@@ -142,7 +145,8 @@ int fftconv_cache_stats(long *plans, long *hits, long *misses, size_t *device_by
  * With plan option / fftconv_plan_options.verbose the same line goes to stderr. */
 typedef struct fftconv_call_timing {
     double plan_ms;        /* cache lookup, or plan creation: tables, kernel set-up, device tables */
-    double image_ms;       /* host-to-device copy of the image + its transform, complete */
+    double image_ms;       /* the image staged / copied and its transform QUEUED (small images go through pinned staging and the
+                              call does not wait for the GPU: the transform's run time then shows in convolve_ms) */
     double convolve_ms;    /* kernel uploads, every map computed and copied into the caller's buffers */
     double release_ms;     /* plan back into the cache, or its teardown */
     double total_ms;
@@ -228,8 +232,13 @@ int fftconv_plan_get_info(const fftconv_plan *plan, fftconv_plan_info *info);
 
 /* Zero-pad + forward transform of the image: padData + cufftExecR2C on the data
  * (src/cudaConvolutionFFT.cu:144-169; src/cudaFFTData.cu:105-147).
- * location: FFTCONV_HOST (pageable or pinned host memory) or FFTCONV_DEVICE. Asynchronous on the
- * plan's stream for device input. */
+ * location: FFTCONV_HOST (pageable or pinned host memory) or FFTCONV_DEVICE.
+ * Ordering: the transform is queued on the plan's stream and the call may return before it has run, for device AND host
+ * input.  Host input: `data` has been consumed when the call returns (copied, or staged in the plan's pinned buffer -- images
+ * up to 1 MiB -- in which case the call does not wait for the GPU at all); the spectrum is ordered on the plan's stream like
+ * any other work of the plan.  A caller that reads fftconv_plan_spectrum() on ANOTHER stream orders that stream behind the
+ * plan's (an event, or fftconv_plan_synchronize) whatever the location.  Device input: `data` must stay valid until the
+ * stream has passed the transform. */
 int fftconv_plan_set_image(fftconv_plan *plan, const float *data, int location);
 
 /* Device pointer + size of the image spectrum (library-owned, valid until destroy).  This is the

@@ -814,9 +814,20 @@ def test_blockwise_plan_api_every_entry(fc, oracle, shape):
         p.synchronize()
         for j, r in enumerate(ref2):
             assert util.rel_err(out[j].cpu().numpy().T, r) < TIGHT
-        with pytest.raises(fc.FFTConvError) as ei:
-            p.set_option("output_region", 1)
-        assert ei.value.status == -5
+        # "output_region" on a block-wise plan (overlap-add here): the region is cropped out of the full-window maps on delivery
+        for region, (oh, ow, o_h, o_w) in {1: (H + kh - 1, W + kw - 1, 0, 0), 2: (H, W, (kh - 1) // 2, (kw - 1) // 2),
+                                           3: (H - kh + 1, W - kw + 1, kh - 1, kw - 1)}.items():
+            p.set_option("output_region", region)
+            assert p.get_option("output_region") == region and (p.info.out_h, p.info.out_w) == (oh, ow) and p.info.out_map_bytes == oh * ow * 4
+            for g, r in zip(p.convolve(ks), ref2):
+                assert g.shape == (oh, ow) and util.rel_err(g, r[o_h:o_h + oh, o_w:o_w + ow]) < TIGHT * max(1.0, np.abs(r).max() / np.abs(r[o_h:o_h + oh, o_w:o_w + ow]).max())
+            od = torch.full((n, ow, oh), float("nan"), dtype=torch.float32, device=dev)
+            p.convolve_packed_device(n, k_d.data_ptr(), kh, kw, od.data_ptr())
+            p.synchronize()
+            for j, r in enumerate(ref2):
+                assert util.rel_err(od[j].cpu().numpy().T, r[o_h:o_h + oh, o_w:o_w + ow]) < TIGHT * max(1.0, np.abs(r).max() / np.abs(r[o_h:o_h + oh, o_w:o_w + ow]).max())
+        p.set_option("output_region", 0)
+        assert (p.info.out_h, p.info.out_w) == (fh, fw)
         with pytest.raises(fc.FFTConvError) as ei:          # a kernel beyond MAX_KERNEL cannot be folded block-wise
             p.convolve([np.zeros((kh + 1, kw, F), np.float32)])
         assert ei.value.status == -4
@@ -919,6 +930,22 @@ def test_large_sizes_run_in_blocks_where_the_cost_model_says_so(fc, oracle):
     assert float((outs[0] - outs[1]).abs().max() / outs[1].abs().max()) < 2e-6
     ref = oracle.conv_fft(data, K, K, ks[:1])[0]
     assert util.rel_err(outs[0][0].cpu().numpy().T, ref) < TIGHT
+    # the options of a one-pass plan hold on the plan the planner turned block-wise by itself (overlap-save): "output_region"
+    # full (demoCudaConvolutionFFT.m:149) and same, packed device maps and host maps, and the window again afterwards
+    with fc.Plan(H, W, 1, K, K) as p:
+        assert p.get_option("blockwise") > 1 and p.get_option("overlap_save") == 1
+        p.set_image_device(img_d.data_ptr())
+        for region, (oh, ow, o_h, o_w) in {1: (H + K - 1, W + K - 1, 0, 0), 2: (H, W, (K - 1) // 2, (K - 1) // 2)}.items():
+            p.set_option("output_region", region)
+            assert (p.info.out_h, p.info.out_w) == (oh, ow) and p.info.out_map_bytes == oh * ow * 4
+            od = torch.full((n, ow, oh), float("nan"), dtype=torch.float32, device=dev)
+            p.convolve_packed_device(n, k_d.data_ptr(), K, K, od.data_ptr())
+            p.synchronize()
+            assert torch.equal(od, outs[0][:, o_w:o_w + ow, o_h:o_h + oh])
+        got = p.convolve(ks[:1])[0]                      # region 2 ("same"), host map
+        assert got.shape == (H, W) and np.array_equal(got, outs[0][0].cpu().numpy().T[o_h:o_h + H, o_w:o_w + W])
+        p.set_option("output_region", 0)
+        assert (p.info.out_h, p.info.out_w) == (4976, 4976)
 
 
 # ---- output_region: full / same / valid parts of the padded window ---------------------------------
@@ -1255,6 +1282,43 @@ def test_one_shot_plan_cache(fc, oracle):
     assert fc.cache_stats()["plans"] == 1
     fc.cache_clear()
     assert fc.cache_stats()["plans"] == 0 and fc.cache_stats()["device_bytes"] == 0
+
+
+def test_cached_plans_go_when_the_device_runs_out_of_memory(fc, oracle):
+    """The one-shot entry keeps idle plans with gigabytes of device scratch, where the reference releases everything between
+    calls (src/cudaConvolutionFFT.cu:302-310).  That must never cost a later call its memory: with the device filled up to
+    less than the next call needs, the call still succeeds -- the idle plan is released when an allocation fails and the
+    request repeated -- and matches the oracle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    fc.cache_clear()
+    fc.cache_configure(4)
+    H, W, kh, kw, n = 2048, 2048, 31, 31, 32
+    img, ks = util.synth(811, H, W, 1, kh, kw, n)
+    fh, fw = util.ceil16(H + kh - 1), util.ceil16(W + kw - 1)
+    outs = [np.empty((fh, fw), dtype=np.float32, order="F") for _ in range(n)]
+    fc.cudaConvolutionFFT(img, kh, kw, ks, out=outs)
+    held = fc.cache_stats()
+    assert held["plans"] == 1 and held["device_bytes"] > (1 << 30)
+    D = held["device_bytes"]
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info(dev)
+    hog = torch.empty(free - int(0.35 * D), dtype=torch.uint8, device=dev)       # what is left is a third of what the next call needs
+    try:
+        H2 = 2040                                                                 # another problem size: another plan, about as large
+        img2, _ = util.synth(812, H2, H2, 1, kh, kw, 1)
+        outs2 = [np.empty((util.ceil16(H2 + kh - 1), util.ceil16(H2 + kw - 1)), dtype=np.float32, order="F") for _ in range(n)]
+        fc.cudaConvolutionFFT(img2, kh, kw, ks, out=outs2)
+        after = fc.cache_stats()
+        assert after["plans"] == 1 and after["misses"] == held["misses"] + 1      # the first plan went, this call's plan is the idle one now
+        ref = oracle.conv_fft(img2, kh, kw, ks[:2])
+        for g, r in zip(outs2[:2], ref):
+            assert util.rel_err(g, r) < TOL
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        fc.cache_clear()
 
 
 def test_one_shot_plan_cache_blockwise_and_threads(fc, oracle):
