@@ -15,7 +15,8 @@ for arg in sys.argv[1:]:
             assert r1 * r2 * r3 == L and rpw * r1 * r2 <= nt and r3 % 2 == 0, item
             pat = re.compile(r"(    X\(%d, [^\n]*\\\n)+" % L)
             m = pat.search(s); assert m, item
-            nz = sorted(set([min(3, r2), r2]))
+            # NZ2 variants: what 31 / 63 / 127-wide kernels need at this R3 (kernel width <= NZ2 * R3), and the unpruned form
+            nz = sorted(set([min(r2, max(1, -(-k // r3))) for k in (31, 63, 127)] + [min(3, r2), r2]))
             new = "".join("    X(%d, %d, %d, %d, %d, %d, %d) \\\n" % (L, r1, r2, r3, nt, rpw, z) for z in nz)
             tail = s[m.end():]
             if not m.group(0).rstrip().endswith("\\"):       # last line of a macro (no continuation)
