@@ -25,8 +25,10 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 // stage-2 inputs the variant reads (kernel width <= NZ2 * R3), listed ascending per length (the dispatcher takes the first that
 // covers the kernel).  What shaped the list (HISTORY.md; A/B files under profiles/):
 //   * BASELINE: 4224 = 8.24.22 (cfg3; cfg4's 4160 window runs on it and crops), 2112 = 8.12.22 x2 (cfg5), 1152 = 8.12.12 x2 (cfg2's
-//     1088 window), 288 = 4.6.12 x8 (cfg1).  4160 = 10.16.26 and 1088 = 17.4.16 x2 are those two windows' OWN kernels: 10-19 % slower
-//     than the convenient length + crop (r04b_native_window_ab.txt), used by exact_window plans only (planner factors above).
+//     1088 window), 288 = 4.6.12 x8 (cfg1).  4160 = 8.20.26 and 1088 = 8.17.8 are those two windows' OWN kernels (round 5's search over
+//     their radix splits, r05d_native_window_search.txt: 10.16.26 -> 8.20.26 -4 %, 17.4.16 x2 -> 8.17.8 -2 %; 16.10.26, 5.32.26, 8.26.20,
+//     20.8.26, 16.13.20, 13.16.20 and 4.17.16, 17.4.16 x3 measured slower): still slower than the convenient length + crop
+//     (r05e_native_window_ab.txt), used by exact_window plans only (planner factors above).
 //   * Round 4 filled the ladder (r04z_size_sweep.txt): a transform is at most ~1.13 x the padded size per dimension above 1000 pixels.
 //   * Long rows: 160 KB of LDS hold two rows of >= 7040 points (one 640- / 768-thread workgroup per CU); 5120 ... 6144 run one row per
 //     256-thread workgroup, three workgroups per CU (r04g: -11 ... -25 % against the R1 = 16 forms on 320 / 384 threads).  More than
@@ -68,8 +70,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(4224, 8, 24, 22, 192, 1, 3)   \
     X(4224, 8, 24, 22, 192, 1, 6)   \
     X(4224, 8, 24, 22, 192, 1, 24)  \
-    X(4160, 10, 16, 26, 192, 1, 3)  \
-    X(4160, 10, 16, 26, 192, 1, 16) \
+    X(4160, 8, 20, 26, 192, 1, 3)   \
+    X(4160, 8, 20, 26, 192, 1, 5)   \
+    X(4160, 8, 20, 26, 192, 1, 20)  \
     X(3840, 8, 24, 20, 192, 1, 4)   \
     X(3840, 8, 24, 20, 192, 1, 24)  \
     X(3520, 10, 16, 22, 192, 1, 3)  \
@@ -103,8 +106,9 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
     X(1152, 8, 12, 12, 192, 2, 3)   \
     X(1152, 8, 12, 12, 192, 2, 6)   \
     X(1152, 8, 12, 12, 192, 2, 12)  \
-    X(1088, 17, 4, 16, 192, 2, 2)   \
-    X(1088, 17, 4, 16, 192, 2, 4)   \
+    X(1088, 8, 17, 8, 192, 1, 4)    \
+    X(1088, 8, 17, 8, 192, 1, 8)    \
+    X(1088, 8, 17, 8, 192, 1, 17)   \
     X(960, 6, 16, 10, 192, 2, 4)    \
     X(960, 6, 16, 10, 192, 2, 7)    \
     X(960, 6, 16, 10, 192, 2, 16)   \
@@ -249,7 +253,11 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
 //     them.  M = 1152 as 8.8.18 / T = 16, 576 as 4.8.18 and 288 as 6.8.6 measured no better than the listed forms.
 //   * The same search (r04i_config_search_*.txt): M = 3520 as 10.16.22 (-4 %), 1760 as 5.16.22 (-6 %); 1056 as 3.16.22, 1152 as 12.8.12,
 //     576 as 3.16.12 / 4.12.12, 1408 as 4.16.22 within noise over three repetitions and left alone.
-//   * M = 2080 = 8.10.26 and 544 = 2.17.16: the cfg4 / cfg2 windows' own kernels (exact_window plans); 2080 spills 12 registers.
+//   * M = 2080 = 8.13.20 (832 threads) and 544 = 17.4.8 (8 columns): the cfg4 / cfg2 windows' own kernels (exact_window plans).  Round 5
+//     (r05d_native_window_search.txt): 8.10.26 (radix 26 beside seven rounds of prefetch: 12 spilled registers) -> 8.13.20 on 832 threads
+//     (128 registers: 4 spilled), -12 % (13.8.20 -11 %, 4.20.26 -6 %, 5.16.26 / 10.8.26 +-1 %, 4.26.20 +23 %); 544 as 8-column tiles 17.4.8: the output
+//     kernel itself +6 % at 64 maps, but the forward column passes (image, kernels) get twice the tiles: the step -1 % at 64 maps,
+//     -11 % at cfg2's 16 (2.17.16 / 17.2.16 at 16 columns: no difference).
 #define FC_FAST_COL_CONFIGS_G0(X) \
     X(4224, 8, 24, 22, 4, 768)    \
     X(3840, 8, 24, 20, 4, 768)    \
@@ -259,7 +267,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(2560, 8, 32, 10, 4, 1024)    \
     X(2304, 8, 16, 18, 8, 1024)    \
     X(2112, 6, 16, 22, 8, 768)    \
-    X(2080, 8, 10, 26, 8, 640)    \
+    X(2080, 8, 13, 20, 8, 832)    \
     X(1920, 8, 12, 20, 8, 768)    \
     X(1760, 5, 16, 22, 8, 640)    \
     X(1680, 6, 20, 14, 8, 960)
@@ -275,7 +283,7 @@ inline FastRowsTables make_fast_rows_tables(const FastRowsInfo& fi, const Plan1D
     X(672, 6, 8, 14, 16, 768)     \
     X(640, 8, 8, 10, 16, 1024)    \
     X(576, 6, 8, 12, 16, 768)     \
-    X(544, 2, 17, 16, 16, 544)    \
+    X(544, 17, 4, 8, 8, 544)      \
     X(480, 6, 8, 10, 16, 768)     \
     X(432, 6, 6, 12, 16, 576)     \
     X(384, 4, 8, 12, 16, 512)     \

@@ -367,9 +367,12 @@ def test_hot_kernels_do_not_spill():
     hot = {k: v for k, v in rep.items() if any(s in k for s in ("k_fast_rows_multiI", "k_fast_colsI", "k_fast_cols_fwdI", "k_fast_rows_fwdI"))}
     assert len(hot) > 40, len(hot)
     bad = {k: v for k, v in hot.items() if v.get("spill", 0) != 0 or v.get("scratch", 0) != 0 or v.get("occ", 0) < 3}
-    # the one exception: the output kernel of cfg4's own window (M = 2080 = 8.10.26, used by exact_window plans only -- default plans
-    # run that window on the 4224-point kernels): its radix-26 stage beside seven rounds of prefetch does not fit 168 registers
-    known = {k: v for k, v in bad.items() if "k_fast_colsINS_6ColCfgILi2080E" in k and v.get("spill", 0) <= 24 and v.get("occ", 0) >= 3}
+    # the one exception: the output kernel of cfg4's own window (M = 2080, used by exact_window plans only -- default plans run that
+    # window on the 4224-point kernels).  Round 5: 8.13.20 on 832 threads (13 waves: 128 registers): 4-5 spilled registers in the
+    # tiled variants (six rounds of prefetch registers for 5.005 rounds of gather units), 12 in the row-major one -- against 12-21
+    # for round 4's 8.10.26, and 12 % faster (profiles/r05d_native_window_search.txt; 13.8.20: 7-14, 4.20.26: 10-19)
+    known = {k: v for k, v in bad.items() if "k_fast_colsINS_6ColCfgILi2080E" in k and v.get("occ", 0) >= 3 and
+             v.get("spill", 0) <= (12 if "ELb0ELb0EEEv" in k else 5)}
     # ... and the ROW-MAJOR-intermediate variant (template argument TILED = false: generic row kernel beside a specialised column
     # kernel) of M = 3072 = 8.32.12 on 1024 threads (128 registers): 2 spilled registers; the tiled variant, the default, has none
     known.update({k: v for k, v in bad.items() if "k_fast_colsINS_6ColCfgILi3072E" in k and "ELb0ELb0EEEv" in k and v.get("spill", 0) <= 4})
