@@ -539,7 +539,6 @@ def main():
                          "default run reports this figure as value_kernels_resident)")
     ap.add_argument("--no-host-output", action="store_true", help="skip the host-in / host-out figures (host_output)")
     ap.add_argument("--no-multi-feature", action="store_true", help="skip the F > 1 figures (multi_feature)")
-    ap.add_argument("--y-spacer-mb", type=int, default=0, help="plan option intermediate_spacer_mb (placement experiment)")
     ap.add_argument("--dynamic-tiles", type=int, default=-1,
                     help="plan option dynamic_tiles: the persistent column kernels take their tiles from a queue (1) or by the static "
                          "deal (0: A/B); -1 = the library's default (1)")
@@ -633,8 +632,6 @@ def main():
         plan.set_option("kernel_chunk_mb", args.kernel_chunk_mb)
     if args.dynamic_tiles >= 0:
         plan.set_option("dynamic_tiles", args.dynamic_tiles)
-    if args.y_spacer_mb > 0:
-        plan.set_option("intermediate_spacer_mb", args.y_spacer_mb)
     hog = None
     hog_cfg = None
     side_work = None

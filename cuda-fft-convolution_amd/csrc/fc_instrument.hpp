@@ -9,7 +9,7 @@
 #if !defined(FC_INSTRUMENT)
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
-    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_STAGGER)
+    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -52,14 +52,6 @@
 // 56.7 / 53.2 / 54.6 us per map at F = 4 on one box (profiles/r03i_f4_image_row_load_placement.txt)
 #ifndef FC_MULTIF_S_EARLY
 #define FC_MULTIF_S_EARLY 4
-#endif
-// Start stagger of the first round of row workgroups.  The ~1000 workgroups a launch begins with start together, four per CU,
-// and run their phases in lockstep (all in the LDS-heavy part, then all in the arithmetic) until they have drifted apart:
-// the stamped workgroup of tools/rows_timeline.py takes ~18 us per map for its first 9 maps and ~11 after that
-// (profiles/r05d_rows_timeline.txt).  k-th arrival on a CU (linear block index / 256, the dispatcher fills CUs breadth-first)
-// sleeps k x FC_ROWS_STAGGER x 2048 clocks before it starts; 0: off.
-#ifndef FC_ROWS_STAGGER
-#define FC_ROWS_STAGGER 0
 #endif
 #ifndef FC_ROWS_TIMELINE
 #define FC_ROWS_TIMELINE 0       // 1: one workgroup stamps the wall clock at every phase boundary (tools/rows_timeline.py)

@@ -152,16 +152,7 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     FC_VERBOSE(p, "N Kernel: %d (maps per launch %d, kernels per column-spectrum chunk %d, %s)", n, nbY, nbA,
                sink.packed ? "packed device output" : sink.location == FFTCONV_HOST ? "host output" : "device output");   // :68
     if (int rc = p->A.ensure(per_a * nbA)) return rc;
-    {
-        // experiment (option "intermediate_spacer_mb"): the intermediate behind a transient allocation of that size, so that it
-        // does not come from the memory right behind the caller's map buffer (the output kernel's two placement states)
-        void* spacer = nullptr;
-        if (p->opt_y_spacer_mb > 0 && g.y_elems_per_kernel() * nbY > p->Y.cap)
-            if (hipMalloc(&spacer, (size_t)p->opt_y_spacer_mb << 20) != hipSuccess) { (void)hipGetLastError(); spacer = nullptr; }
-        const int rcy = p->Y.ensure(g.y_elems_per_kernel() * nbY);
-        if (spacer) (void)hipFree(spacer);
-        if (rcy) return rcy;
-    }
+    if (int rc = p->Y.ensure(g.y_elems_per_kernel() * nbY)) return rc;
     const OutWindow* win = p->win;
     if (win && !g.fast_cols.ok) return api_fail(FFTCONV_ERR_INVALID_ARG, "an output window needs the specialised output kernel");
     const bool staged = (sink.packed == nullptr) && !win;
@@ -844,7 +835,6 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         return fftconv_plan_set_option(plan->tiled->sub, name, value);
     }
     if (!strcmp(name, "tune_placement")) { plan->opt_tune_placement = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }
-    if (!strcmp(name, "intermediate_spacer_mb")) { plan->opt_y_spacer_mb = value < 0 ? 0 : value; return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
     if (!strcmp(name, "profile")) {
@@ -930,7 +920,6 @@ int fftconv_plan_get_option(fftconv_plan* plan, const char* name, long* value) {
     if (!strcmp(name, "batch_maps")) { *value = plan->opt_batch_maps; return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { *value = plan->opt_kernel_chunk_mb; return 0; }
     if (!strcmp(name, "tune_placement")) { *value = plan->opt_tune_placement; return 0; }
-    if (!strcmp(name, "intermediate_spacer_mb")) { *value = plan->opt_y_spacer_mb; return 0; }
     if (!strcmp(name, "tuned_candidates")) { *value = plan->tuned_candidates; return 0; }
     if (!strcmp(name, "tuned_best")) { *value = plan->tuned_best; return 0; }
     if (!strcmp(name, "rows_group")) { *value = plan->g.rows_group; return 0; }

@@ -213,7 +213,6 @@ struct fftconv_plan {
     long opt_batch_maps = 0;
     long opt_kernel_chunk_mb = 0;
     int tuned_candidates = 0, tuned_best = 0;   // of the last placement tuning (fftconv_plan_get_option)
-    long opt_y_spacer_mb = 0;      // experiment: transient allocation in front of the intermediate's (option "intermediate_spacer_mb")
     long opt_tune_placement = 0;   // > 1: that many candidate allocations of the intermediate are tried (tune_intermediate_placement)
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
     long opt_host_min_kb = FC_HOST_MIN_KB;   // maps smaller than this leave by blocking copies whatever host_stream says
