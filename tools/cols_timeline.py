@@ -8,10 +8,14 @@ import numpy as np, torch
 dbg = torch.zeros(16 * 8, dtype=torch.int64, device="cuda")
 import util
 fc = util.load_package()
-H = W = 4096; kh = kw = 127; n = 64
+# usage: cols_timeline.py [H K maps]  (default: cfg3; large sizes are forced to one pass)
+H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+kh = kw = int(sys.argv[2]) if len(sys.argv) > 2 else 127
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 img = torch.rand((1, W, H), dtype=torch.float32, device="cuda")
 ker = torch.rand((n, 1, kw, kh), dtype=torch.float32, device="cuda")
-plan = fc.Plan(H, W, 1, kh, kw, stream=torch.cuda.current_stream().cuda_stream)
+plan = fc.Plan(H, W, 1, kh, kw, stream=torch.cuda.current_stream().cuda_stream, options={"blockwise": 1})
+print("image %d x %d, kernels %d x %d, %d maps: transform %d x %d" % (H, W, kh, kw, n, plan.info.transform_h, plan.info.transform_w))
 out = torch.empty((n, plan.info.fft_w, plan.info.fft_h), dtype=torch.float32, device="cuda")
 plan.set_option("timeline_ptr", dbg.data_ptr())   # exists in FC_*_TIMELINE builds only
 for rep in range(3):
