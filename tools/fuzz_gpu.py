@@ -82,10 +82,11 @@ def draw_case(rng, max_pixels):
         region = 0
     if cls == "large":
         opts.pop("max_transform", None)
-        if not opts["blockwise"]:
-            region = 0                      # the planner may choose blocks: no regions there
+        if not opts["blockwise"]:           # (the planner may choose blocks by itself: regions are cropped on delivery there, round 5)
             if rng.random() < 0.2:
                 opts["max_transform"] = int(rng.choice([1152, 2112]))
+    elif "max_transform" not in opts and rng.random() < 0.15:
+        opts["exact_window"] = 1            # the window's own transform (the BASELINE windows 1088 / 4160 have kernels of their own)
     return dict(cls=str(cls), H=H, W=W, F=F, mkh=mkh, mkw=mkw, sizes=sizes, entry=entry, opts=opts, runtime=runtime, region=region)
 
 
@@ -95,8 +96,16 @@ def run_case(fc, oracle, torch, case, rng):
     ks = [rng.standard_normal((kh, kw, F)).astype(np.float32) for kh, kw in case["sizes"]]
     entry, opts, rt, region = case["entry"], dict(case["opts"]), dict(case["runtime"]), case["region"]
     blockwise_forced = "max_transform" in opts
-    if entry in ("one_shot", "two_step") or blockwise_forced:
-        region = 0                      # (the one-shot and two-step entries return the window; block-wise plans have no regions)
+    if opts.get("exact_window"):        # windows with a prime factor above 17 have no transform of their own: the documented refusal, then without
+        try:
+            with fc.Plan(H, W, F, mkh, mkw, options=opts):
+                pass
+        except fc.FFTConvError as e:
+            if e.status != -5:
+                raise
+            opts.pop("exact_window")
+    if entry in ("one_shot", "two_step"):
+        region = 0                      # (the one-shot and two-step entries return the window)
     if entry == "plan_device" and len(set(case["sizes"])) != 1:
         entry = "plan_host"             # the packed device entry takes kernels of one size
     flip = rt["flip_kernels"] and entry in ("plan_host", "plan_device") and not blockwise_forced
