@@ -413,14 +413,15 @@ def test_bench_counts_distinct_devices_by_pci_id_then_by_index():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """the round's committed bench line (profiles/r04z_cfg3_bench.json, written by tools/profile_round.sh on the GPU box) carries
+    """the newest committed bench line (profiles/r<NN>z_cfg3_bench.json, written by tools/profile_round.sh on the GPU box) carries
     every key the driver's contract names, the roofline and the CPU baseline objects, and numbers that are consistent with
     each other"""
+    import glob
     import json
-    path = os.path.join(util.ROOT, "profiles", "r04z_cfg3_bench.json")
-    if not os.path.exists(path):
+    lines = sorted(glob.glob(os.path.join(util.ROOT, "profiles", "r[0-9][0-9]z_cfg3_bench.json")))
+    if not lines:
         pytest.skip("no committed bench line")
-    j = json.loads(open(path).read().strip().splitlines()[-1])
+    j = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -432,6 +433,10 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["traffic"] is None or 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2      # no wasted re-reads
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
+    if "faithful_variants" in c:      # round 5: value = the fastest of the complex128 full-spectrum variants, each with its cores
+        fv = {k: v for k, v in c["faithful_variants"].items() if "value" in v}
+        assert c["value_from"] in fv and abs(c["value"] - max(v["value"] for v in fv.values())) < 1e-12
+        assert "scipy_pocketfft_c128_full" in c["faithful_variants"] and all(v["cores"] >= 1 for v in fv.values())
     # value = maps x padded pixels / step time
     maps, P = 256, 4224 * 4224
     assert abs(j["value"] - maps * P / (j["ms_per_step"] * 1e-3) / 1e9) / j["value"] < 1e-3
