@@ -23,7 +23,7 @@ constexpr double FC_FACTOR_1088 = 0.60, FC_FACTOR_4160 = 0.60;
 // X(L, R1, R2, R3, NT, RPW, NZ2): see fast_rows.hpp.  RPW rows of L = R1 x R2 x R3 points per workgroup of NT threads, chosen so that
 // RPW * R1 * R2 (the stage-3 butterflies, one per thread) fill the lanes and stage 2 takes one round where possible; NZ2 = non-zero
 // stage-2 inputs the variant reads (kernel width <= NZ2 * R3), listed ascending per length (the dispatcher takes the first that
-// covers the kernel).  What shaped the list (HISTORY.md; A/B files under profiles/):
+// covers the kernel).  What shaped the list (history/; A/B files under profiles/):
 //   * BASELINE: 4224 = 8.24.22 (cfg3; cfg4's 4160 window runs on it and crops), 2112 = 8.12.22 x2 (cfg5), 1152 = 8.12.12 x2 (cfg2's
 //     1088 window), 288 = 4.6.12 x8 (cfg1).  4160 = 8.20.26 and 1088 = 8.17.8 are those two windows' OWN kernels (round 5's search over
 //     their radix splits, r05d_native_window_search.txt: 10.16.26 -> 8.20.26 -4 %, 17.4.16 x2 -> 8.17.8 -2 %; 16.10.26, 5.32.26, 8.26.20,

@@ -440,13 +440,15 @@ int fc::plan_create_internal(fftconv_plan** plan, int data_h, int data_w, int fe
             if ((rc = p->fc_pair_row_of.ensure(ft.pair_row_of.size()))) break;
             if ((rc = cp(p->fc_pair_row_of.p, ft.pair_row_of.data(), ft.pair_row_of.size() * sizeof(int)))) break;
             p->d.fc_pair_row_of = p->fc_pair_row_of.p;
-            // dynamic tile queue of the persistent column kernels: on by default (option "dynamic_tiles"; alone on the GPU it
-            // measures equal or up to 2 % faster than the static deal, beside another kernel it loses half as much:
-            // profiles/r05a_contention_ab.txt).  Zeroed once; every launch leaves the counters at zero.
+            // Dynamic tile queue of the persistent OUTPUT kernel (option "dynamic_tiles"): on by default where a tile is long enough
+            // for its one-ahead ticket to arrive in time -- M >= 432.  Alone on the GPU it then measures equal or up to 3 % faster
+            // than the static deal, beside another kernel it loses half as much (profiles/r05a_contention_ab.txt); on the short
+            // tiles of small transforms (M = 336: +18 %, cfg1's M = 144: +4 us a launch) it does not pay
+            // (profiles/r05k_dynamic_tiles_by_size.txt).  Zeroed once; every launch leaves the counters at zero.
             if ((rc = p->queue.ensure(FC_QUEUE_WORDS))) break;
             if (hipMemset(p->queue.p, 0, FC_QUEUE_WORDS * sizeof(int)) != hipSuccess) { rc = api_fail(FFTCONV_ERR_HIP, "hipMemset of the tile queue failed"); break; }
-            p->opt_dynamic_tiles = 1;
-            p->d.queue = p->queue.p;
+            p->opt_dynamic_tiles = p->g.M >= 432 ? 1 : 0;
+            p->d.queue = p->opt_dynamic_tiles ? p->queue.p : nullptr;
         }
         if (p->g.fast_rows.ok && p->g.F == 1) {   // resident workgroups per CU of the multi-map row kernel: what rows_group_auto deals over
             FastRowsArgs qa = fast_rows_args(p->g, p->d, nullptr, p->g.max_kw, nullptr, nullptr);
@@ -847,18 +849,20 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     }
     if (!strcmp(name, "verbose")) { plan->opt_verbose = value != 0; return 0; }
     if (!strcmp(name, "dynamic_tiles")) {
-        // the persistent column kernels (output columns; image and kernel columns forwards) take their tiles from a queue in
-        // device memory (1, the default where the plan has specialised column kernels) instead of a fixed share per workgroup
-        // (0): see fast_cols.hpp: TileQueue.  A step that shares the GPU with another kernel -- the broadcast of a multi-GPU
-        // run, another library's work -- loses half as much with the queue; 0 is kept for A/B runs.
+        // 1: the persistent output kernel takes its tiles from a queue in device memory (fast_cols.hpp: TileQueue; the default
+        // from M = 432 on) instead of a fixed share per workgroup (0); 2: the forward column kernels (image, kernels) too.  A step
+        // that shares the GPU with another kernel -- the broadcast of a multi-GPU run, another library's work -- loses half as much
+        // with the queue.
+        if (value < 0 || value > 2) return api_fail(FFTCONV_ERR_INVALID_ARG, "dynamic_tiles is 0, 1 or 2");
         if (value && !plan->g.fast_cols.ok) value = 0;      // (generic kernels: one workgroup per tile, dealt by the hardware)
         if (value && !plan->queue.p) {     // zeroed once: every launch leaves the counters at zero (fast_cols.hpp: queue_leave)
             if (int rc = use_device(plan)) return rc;
             if (int rc = plan->queue.ensure(FC_QUEUE_WORDS)) return rc;
             HIP_TRY(hipMemset(plan->queue.p, 0, FC_QUEUE_WORDS * sizeof(int)));
         }
-        plan->opt_dynamic_tiles = value != 0;
+        plan->opt_dynamic_tiles = value;
         plan->d.queue = value ? plan->queue.p : nullptr;
+        plan->d.queue_fwd = value == 2;
         return 0;
     }
     if (!strcmp(name, "defer_prepare")) {

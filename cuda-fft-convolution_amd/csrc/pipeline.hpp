@@ -191,6 +191,7 @@ struct DeviceTables {
     const int* fc_rowoff = nullptr;
     const int* fc_pair_row_of = nullptr;
     int* queue = nullptr;                     // dynamic tile queue of the persistent column kernels (FC_QUEUE_WORDS ints; plan option "dynamic_tiles")
+    bool queue_fwd = false;                   // ... also for the forward column kernels ("dynamic_tiles" = 2; off by default, see fast_cols_fwd_args)
     unsigned long long* timeline = nullptr;   // FC_ROWS_TIMELINE / FC_COLS_TIMELINE builds only (plan option "timeline_ptr")
 };
 
@@ -287,7 +288,11 @@ inline FastColsFwdArgs fast_cols_fwd_args(const Geometry& g, const DeviceTables&
     a.out = out; a.out_plane_stride = out_plane_stride; a.out_pitch = out_pitch;
     a.tiles_per_plane = (ncols + g.fast_cols.T - 1) / g.fast_cols.T; a.ntiles = a.tiles_per_plane * planes;
     a.tw1 = d.fc_tw1; a.tw2 = d.fc_tw2; a.pairs = d.fc_pairs;
-    a.queue = d.queue ? d.queue + (of_kernels ? 9 : 8) * FC_QUEUE_STRIDE : nullptr;
+    // The forward kernels take their tiles from ONE counter each, and their tiles are short (a pruned kernel column pass is ~2 us a
+    // tile): the 1 024 tickets of a 64-kernel pass queue up on that one cache line -- +12 us per pass at every size, +6-10 us per
+    // image pass (profiles/r05k_dynamic_tiles_by_size.txt).  They are 1-3 % of a step and lose next to nothing to a neighbour
+    // that holds CUs: static deal unless "dynamic_tiles" = 2 asks for the queue (A/B, tests).
+    a.queue = (d.queue && d.queue_fwd) ? d.queue + (of_kernels ? 9 : 8) * FC_QUEUE_STRIDE : nullptr;
     return a;
 }
 

@@ -206,7 +206,7 @@ struct fftconv_plan {
     DevBuf<PairEntry> fc_pairs;
     DevBuf<int> fc_rowoff, fc_pair_row_of;
     DevBuf<int> queue;                    // counters of the dynamic tile queue (option "dynamic_tiles"; allocated when it is first set)
-    long opt_dynamic_tiles = 0;           // 1: the persistent column kernels take their tiles from a queue (fast_cols.hpp: TileQueue)
+    long opt_dynamic_tiles = 0;           // 1: the persistent output kernel takes its tiles from a queue (fast_cols.hpp: TileQueue); 2: the forward column kernels too
     DevBuf<int> nat_row_of, nat_col_of;   // natural-order spectrum exchange (uploaded on first use)
     DevBuf<c32> NS;                       // its device staging for host callers
     int num_cus = 256;

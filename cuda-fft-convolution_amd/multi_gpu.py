@@ -102,7 +102,7 @@ class FilterShardedConvolver:
         self.time_broadcast = time_broadcast
         self.side_work = side_work
         # (the step shares the GPU with the collective's kernels: the plan's persistent column kernels take their tiles from
-        #  a queue -- plan option "dynamic_tiles", on by default -- so a CU the collective holds delays nobody's share)
+        #  a queue -- plan option "dynamic_tiles", on by default from 864-point transforms on -- so a CU the collective holds delays nobody's share)
         self._bc_wall, self._bc_events = [], []
         self.first, self.count = filter_shard(n_filters, rank, world)
         self.depth = max(1, int(depth))

@@ -312,12 +312,15 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             allocation; transient device memory while it runs: k intermediates plus k - 1 spacer allocations of at
  *             most 12 GiB (an eighth of what is free) each; skipped inside a stream capture; 0 (default): off),
  *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
- *          "dynamic_tiles" (1, default where the plan runs the specialised column kernels: their persistent workgroups take
- *             tiles from a queue in device memory -- one counter per XCD, chunks of adjacent tiles, work stealing at the end --
- *             instead of a fixed 1 / grid share each.  A workgroup whose CU is held by another kernel (the RCCL broadcast of a
- *             multi-GPU step, src/cudaConvFFTDataStreams.cu:279-289,338-447; another library) then delays nobody's tiles:
- *             beside 16-32 foreign workgroups a cfg4 step loses 2.5 % instead of 4.5-7 %, alone it runs equal or up to 2 % faster
- *             (profiles/r05a_contention_ab.txt).  0: the static deal, kept for A/B runs; results are identical bit for bit),
+ *          "dynamic_tiles" (1, the default for transforms of 864 points and more along h (M >= 432): the persistent workgroups of
+ *             the output kernel take their tiles from a queue in device memory -- one counter per XCD, chunks of adjacent tiles,
+ *             work stealing at the end -- instead of a fixed 1 / grid share each.  A workgroup whose CU is held by another
+ *             kernel (the RCCL broadcast of a multi-GPU step, src/cudaConvFFTDataStreams.cu:279-289,338-447; another library)
+ *             then delays nobody's tiles: beside 16-32 foreign workgroups a cfg4 step loses 2.5 % instead of 4.5-7 %, alone it
+ *             runs equal or up to 3 % faster (profiles/r05a_contention_ab.txt).  0: the static deal -- the default of smaller
+ *             transforms, whose tiles are too short for a ticket fetched one tile ahead (profiles/r05k_dynamic_tiles_by_size.txt);
+ *             2: the forward column kernels take their tiles from a counter too (measured slower alone: A/B and tests).
+ *             Results are identical bit for bit),
  *          "profile" (1: time every kernel launch with HIP events on the plan's stream),
  *          "profile_kinds" (bit mask over the indices of fftconv_profile: only those kinds are timed
  *             while "profile" is on, 0 = all -- lets a caller time the hot kernels inside its own timed

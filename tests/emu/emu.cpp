@@ -43,6 +43,7 @@ int emu_image_spectrum(const float* data, int H, int W, int F, int max_kh, int m
     if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     DeviceTables d;
     d.queue = g_dynamic_tiles ? g_queue : nullptr;
+    d.queue_fwd = g_dynamic_tiles;      // (the emulator exercises the forward kernels' queue too: plan option dynamic_tiles = 2)
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
     d.pairs = t.pairs.data();
@@ -82,6 +83,7 @@ int emu_convolve_spectrum(const float* spec, int H, int W, int F, int max_kh, in
     if (!make_geometry(g, t, H, W, F, max_kh, max_kw, g_tune)) return -1;
     DeviceTables d;
     d.queue = g_dynamic_tiles ? g_queue : nullptr;
+    d.queue_fwd = g_dynamic_tiles;      // (the emulator exercises the forward kernels' queue too: plan option dynamic_tiles = 2)
     d.tw_m = t.pm.tw.data();
     d.tw_w = t.pw.tw.data();
     d.pairs = t.pairs.data();

@@ -417,7 +417,7 @@ DYNAMIC_TILE_SHAPES = [(4096, 4096, 1, 63, 70), (4096, 4096, 1, 127, 9), (2048, 
 @pytest.mark.parametrize("shape", DYNAMIC_TILE_SHAPES)
 @pytest.mark.parametrize("defer", [0, 1])
 def test_dynamic_tile_queue_matches_static_deal(fc, oracle, shape, defer):
-    """Plan option "dynamic_tiles" (fast_cols.hpp: TileQueue; the default): the persistent column kernels take their tiles from a
+    """Plan option "dynamic_tiles" (fast_cols.hpp: TileQueue; the default of the output kernel from M = 432 on): the persistent column kernels take their tiles from a
     queue in device memory -- robust where a step shares the GPU with a collective (src/cudaConvFFTDataStreams.cu:279-289,338-447).
     A tile is computed by the same code whoever takes it, so the maps must equal the static deal's BIT FOR BIT; the first
     and the last map also go against the oracle.  defer = 1: the image's and the kernels' column passes in one launch."""
@@ -431,7 +431,7 @@ def test_dynamic_tile_queue_matches_static_deal(fc, oracle, shape, defer):
     ref_out = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=0))
     dyn_out = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=1))
     assert torch.equal(ref_out, dyn_out)
-    again = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=1))   # counters zeroed per launch
+    again = _device_run_opts(fc, torch, img.to(dev), ks.to(dev), K, K, dict(base, dynamic_tiles=2))   # counters zeroed per launch; 2: the forward column kernels through their counters too
     assert torch.equal(dyn_out, again)
     if H * W <= 2048 * 2048 or not defer:
         idx = sorted({0, n - 1})
@@ -449,7 +449,8 @@ def test_dynamic_tile_queue_host_entries(fc, oracle):
     ref = oracle.conv_fft(img, 40, 50, ks)
     with fc.Plan(1800, 1700, 1, 40, 50) as p:
         p.set_image(img)
-        for dyn in (1, 0, 1):
+        assert p.get_option("dynamic_tiles") == 1       # the default from 864-point transforms on (here 1920 along h)
+        for dyn in (2, 0, 1):
             p.set_option("dynamic_tiles", dyn)
             if dyn:
                 p.set_image(img)                 # the image's column pass through the queue too

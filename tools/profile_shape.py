@@ -16,6 +16,7 @@ img = torch.from_numpy(rng.random((F, W, H), dtype=np.float32)).to(dev)
 ker = torch.from_numpy(rng.random((n, F, K, K), dtype=np.float32)).to(dev)
 with fc.Plan(H, W, F, K, K, options=opts) as p:
     i = p.info
+    if os.environ.get("DYN"): p.set_option("dynamic_tiles", int(os.environ["DYN"]))      # tile queue of the column kernels on / off (A/B)
     out = torch.empty((n, i.fft_w, i.fft_h), dtype=torch.float32, device=dev)
     def step():
         p.set_image_device(img.data_ptr()); p.convolve_packed_device(n, ker.data_ptr(), K, K, out.data_ptr())
