@@ -38,7 +38,7 @@ struct RowCfg {
     static constexpr int NB3 = R1 * R2;
     static constexpr int RND1 = (RPW * NB1 + NT - 1) / NT;
     static constexpr int RND2 = (RPW * NB2 + NT - 1) / NT;
-    static constexpr int T2N = (R2 - 1) * R3;  // stage-2 twiddle entries
+    static constexpr int T2N = fc_tw2_pitch(R2) * R3;  // stage-2 twiddle image in LDS (fc_common.hpp: fc_tw2_fill)
     static constexpr int LDS_ELEMS = RPW * L + T2N;  // c32
     static_assert(R1 * R2 * R3 == L, "radices must multiply to L");
     static_assert(RPW * NB3 <= NT, "one stage-3 butterfly per thread");

@@ -33,7 +33,7 @@ FC_HD void fast_rows_fwd_body(Ctx& ctx, c32* lds, const FastRowsFwdArgs& g, int 
     // stage 1 (radix R1 over inputs m1 apart, decimation in frequency): block c of the row gets
     // (sum_a x[j + a*m1] w_R1^{a c}) * w_L^{j c}; the loads zero-fill the padding
     ctx.phase([&](int t, State&) {
-        for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
+        fc_tw2_fill<C::R2, C::R3, C::NT>(tw2, g.tw2, t);
         static_for<0, C::RND1>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const int u = t + NT * r;
@@ -76,9 +76,9 @@ FC_HD void fast_rows_fwd_body(Ctx& ctx, c32* lds, const FastRowsFwdArgs& g, int 
                 });
                 Dft<R2, -1>::run(v);
                 p[0] = v[0];
-                static_for<1, R2>([&](auto c_) {
+                fc_tw2_each<R2>(tw2, b, [&](auto c_, c32 w) {
                     constexpr int c = decltype(c_)::value;
-                    p[c * R3] = cmul(v[c], tw2[(c - 1) * R3 + b]);
+                    p[c * R3] = cmul(v[c], w);
                 });
             }
         });

@@ -66,7 +66,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
 
     // once per workgroup: stage-2 twiddles into LDS, first kernel row, image-spectrum row
     ctx.phase_nosync([&](int t, State& st) {
-        for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
+        fc_tw2_fill<R2, R3, NT>(tw2, g.tw2, t);
         load_x(t, st, kernel0, 0);
         // loaded once: inside the walk a global load in P5 would have to be waited for together
         // with the stores issued just before it (one in-order memory counter)
@@ -148,9 +148,9 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     });
                     Dft<R2, -1>::template run_nz<NZ2>(v);   // inputs a >= NZ2 are structural zeros
                     p[0] = v[0];
-                    static_for<1, R2>([&](auto c_) {
+                    fc_tw2_each<R2>(tw2, b, [&](auto c_, c32 w) {
                         constexpr int c = decltype(c_)::value;
-                        p[c * R3] = cmul(v[c], tw2[(c - 1) * R3 + b]);
+                        p[c * R3] = cmul(v[c], w);
                     });
                 }
             });
@@ -274,9 +274,9 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     c32* p = lds + rr * L + c1 * m1 + b;
                     c32 v[R2];
                     v[0] = p[0];
-                    static_for<1, R2>([&](auto c_) {
+                    fc_tw2_each<R2>(tw2, b, [&](auto c_, c32 w) {
                         constexpr int c = decltype(c_)::value;
-                        v[c] = cmulc(p[c * R3], tw2[(c - 1) * R3 + b]);
+                        v[c] = cmulc(p[c * R3], w);
                     });
                     Dft<R2, +1>::run(v);
                     static_for<0, R2>([&](auto a_) {

@@ -236,6 +236,41 @@ struct alignas(16) c32x2 {
     c32 a, b;
 };
 
+// Stage-2 twiddles of the ROW kernels in LDS (round 5): row b holds the twiddles of that b for c = 1 .. R2 - 1 side by side, rows
+// `pitch` entries apart with pitch = 2 (mod 4) -- a thread fetches its R2 - 1 twiddles TWO per 16-byte read (half the LDS
+// instructions of one 8-byte read per twiddle: the stage-2 phases take as long as the arithmetic-heavy stage 3 although they issue a
+// third of its vector instructions -- they are bound by LDS instruction issue, ~5.5 cycles per wave-instruction and CU whatever the
+// width), and the rows of consecutive lanes start 8 (mod 32) banks apart, so the 16-byte reads of a group of lanes do not collide.
+// The global table keeps its [(c - 1) * R3 + b] order.  Row kernels -2 ... -5 % (profiles/r05o_paired_twiddle_reads_ab.txt); the
+// column kernels keep one 8-byte read per twiddle: the same change left the 8- / 16-column ones where they were and cost the
+// 4-column ones 2 %.
+constexpr int fc_tw2_pitch(int R2) {
+    int p = R2 - 1;
+    while (p % 4 != 2) p++;
+    return p;
+}
+template <int R2, int R3, int NT>
+FC_HD void fc_tw2_fill(c32* lds_tw2, const c32* table, int t) {
+    constexpr int P = fc_tw2_pitch(R2);
+    for (int i = t; i < (R2 - 1) * R3; i += NT) {
+        const int c1 = i / R3, b = i - c1 * R3;
+        lds_tw2[b * P + c1] = table[i];
+    }
+}
+// f(c, twiddle) for c = 1 .. R2 - 1, the twiddles of row b read in pairs
+template <int R2, class F>
+FC_HD void fc_tw2_each(const c32* lds_tw2, int b, F&& f) {
+    constexpr int P = fc_tw2_pitch(R2);
+    const c32* row = lds_tw2 + b * P;
+    static_for<0, (R2 - 1) / 2>([&](auto h_) {
+        constexpr int h = decltype(h_)::value;
+        const c32x2 w = *reinterpret_cast<const c32x2*>(row + 2 * h);
+        f(IC<1 + 2 * h>{}, w.a);
+        f(IC<2 + 2 * h>{}, w.b);
+    });
+    if constexpr ((R2 - 1) % 2) f(IC<R2 - 1>{}, row[R2 - 2]);
+}
+
 constexpr int FC_MAX_STAGES = 12;
 
 // One stage of the in-place mixed-radix transform (see fft_lds.hpp).
