@@ -338,6 +338,56 @@ def test_cfg3_full_size_properties(fc, oracle):
     assert util.rel_err(out[0].cpu().numpy().T, ref) < TOL
 
 
+# ---- the vendor's FFT library on the same device as a third, independent statement of the path (test-only: SURVEY 8(c)) ----------
+# The reference's arithmetic lives in cuFFT (src/cudaConvolutionFFT.cu:128,136,167,255,273), which cannot run here; its
+# counterpart on this platform, rocFFT behind hipFFT, is what torch.fft uses on a ROCm device.  This restates the reference's own
+# sequence on it -- zero-pad to [F][FFT_W][FFT_H] (cuh:24-30), R2C with the halved dimension = H (the plan geometry of :122-142),
+# product scaled by 1 / (FFT_W * FFT_H) (cuh:62-65, :270), C2R, sum over the features (cuh:84-90) -- in fp32 as the reference runs
+# it and in fp64, and holds BOTH the product path and the CPU oracle against it.  The library never links or calls it.
+def _vendor_fft_conv(torch, data, mkh, mkw, kernels, dtype):
+    dev = torch.device("cuda", 0)
+    H, W, F = data.shape
+    fh, fw = util.ceil16(H + mkh - 1), util.ceil16(W + mkw - 1)
+    d = torch.zeros((F, fw, fh), dtype=dtype, device=dev)
+    d[:, :W, :H] = torch.from_numpy(np.ascontiguousarray(np.transpose(data, (2, 1, 0)))).to(dev, dtype)
+    D = torch.fft.rfft2(d)                                   # last dimension (h) halved: cuFFT's n = {FFT_W, FFT_H}
+    outs = []
+    for k in kernels:
+        kh, kw = k.shape[0], k.shape[1]
+        kp = torch.zeros((F, fw, fh), dtype=dtype, device=dev)
+        kp[:, :kw, :kh] = torch.from_numpy(np.ascontiguousarray(np.transpose(k, (2, 1, 0)))).to(dev, dtype)
+        prod = D * torch.fft.rfft2(kp)
+        # torch's irfft2 normalises by 1 / (FFT_W * FFT_H): the reference's explicit scale of the product (:270)
+        outs.append(torch.fft.irfft2(prod, s=(fw, fh)).sum(dim=0).cpu().numpy().T)      # [w][h] -> h x w
+    return outs
+
+
+@pytest.mark.parametrize("shape", [
+    (64, 8, 5, 10, 4, 3),          # the demo's problem (demoCudaConvolutionFFT.m:37-42)
+    (256, 256, 1, 31, 31, 1),      # cfg1
+    (1024, 1024, 1, 63, 63, 2),    # cfg2's geometry
+    (2048, 2048, 1, 63, 63, 1),    # cfg5's
+    (4096, 4096, 1, 127, 127, 1),  # cfg3's
+    (4096, 4096, 1, 63, 63, 1),    # cfg4's (window 4160 cropped from a 4224 transform)
+    (300, 260, 3, 31, 17, 2),
+])
+def test_matches_the_vendor_fft_library_on_the_device(fc, oracle, shape):
+    torch = pytest.importorskip("torch")
+    H, W, F, kh, kw, n = shape
+    rng = np.random.default_rng(sum(shape) + 11)
+    data = rng.random((H, W, F), dtype=np.float32)
+    ks = [rng.random((kh, kw, F), dtype=np.float32) for _ in range(n)]
+    got = fc.cudaConvolutionFFT(data, kh, kw, ks)
+    ref32 = _vendor_fft_conv(torch, data, kh, kw, ks, torch.float32)
+    ref64 = _vendor_fft_conv(torch, data, kh, kw, ks, torch.float64)
+    orc = oracle.conv_fft(data, kh, kw, ks)
+    for g, r32, r64, o in zip(got, ref32, ref64, orc):
+        assert g.shape == r32.shape == o.shape
+        assert util.rel_err(g, r64) < TIGHT            # the product against rocFFT in double precision
+        assert util.rel_err(g, r32) < TOL              # ... and against the reference's own precision on the vendor library (north_star's bar)
+        assert util.rel_err(o, r64) < 1e-6             # the CPU oracle against it: two independent float64 statements (the oracle returns fp32 maps)
+
+
 def test_cfg3_headline_launch_geometry(fc, oracle):
     """The launch geometry bench.py times (BASELINE configs[2]): 4096x4096 image, 127x127 kernels,
     84 kernels in one call = one full 64-map launch (four walks of 16 maps per workgroup of the
