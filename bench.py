@@ -29,7 +29,8 @@ need to settle after an idle gap (config.clock_warm_steps).  The timed region is
 
 Order of a run (round 4): set-up -> `cpu_baseline` (CPU only, rank 0 at N = 1) -> W warm-up steps + >= 1 s of settled
 load (`--settle-s`) -> the K timed steps -> checks -> untimed extra passes (`host_output`: the MEX-faithful host-in /
-host-out entry, one-shot and reused plan; `multi_feature`: F > 1, the reference's sumAlongFeatures case).  The timed
+host-out entry, one-shot and reused plan; `multi_feature`: F > 1, the reference's sumAlongFeatures case; `vendor_fft_baseline`: the
+reference's loop ported straight onto the vendor FFT library of the same GPU -- rocFFT through torch.fft -- a baseline like cpu_baseline).  The timed
 step contains the upload of the step's kernels from pinned host memory (double-buffered on an upload
 stream: multi_gpu.HipPlanEngine); `value_kernels_resident` is the same K steps with the kernels kept in HBM.
 
@@ -325,6 +326,43 @@ def host_output_figures(fc, util, np, torch, dev, cases=(("cfg2", 16), ("cfg3", 
         small[name] = e
     res["small_calls"] = small
     fc.cache_clear()
+    return res
+
+
+def vendor_fft_figures(util, np, torch, dev, cfg="cfg3", maps=8, value=None):
+    """The reference's loop as a straight port onto the VENDOR's FFT library of this device (rocFFT behind hipFFT, through torch.fft): every
+    kernel padded to the full plane, R2C, product with the image spectrum, C2R (src/cudaConvolutionFFT.cu:204-291), device-resident, fp32, on a
+    few maps of the configuration -- what a hipify-style port would run, timed on the same GPU right after the headline.  A baseline like
+    cpu_baseline, never `value`; the library itself links and calls no FFT library."""
+    H, W, F, kh, kw, _nf, seed = CONFIGS[cfg]
+    fh, fw = ceil16(H + kh - 1), ceil16(W + kw - 1)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = torch.rand((F, W, H), generator=g, dtype=torch.float32).to(dev)
+    ker = torch.rand((maps, F, kw, kh), generator=g, dtype=torch.float32).to(dev)
+    pad_img = torch.zeros((F, fw, fh), dtype=torch.float32, device=dev)
+    pad_img[:, :W, :H] = img
+    kp = torch.zeros((F, fw, fh), dtype=torch.float32, device=dev)
+    out = torch.empty((maps, fw, fh), dtype=torch.float32, device=dev)
+
+    def loop():
+        D = torch.fft.rfft2(pad_img)
+        for j in range(maps):
+            kp.zero_()
+            kp[:, :kw, :kh] = ker[j]
+            out[j] = torch.fft.irfft2(D * torch.fft.rfft2(kp), s=(fw, fh)).sum(dim=0)
+    loop()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        loop()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    v = maps * fh * fw / dt / 1e9
+    res = {"value": v, "unit": "Gpixel-filters/s", "us_per_map": dt / maps * 1e6, "kind": "port onto the vendor FFT library (rocFFT through torch.fft), same GPU",
+           "sample": "%s image + %d filters, one kernel at a time as the reference's loop, device-resident, fp32" % (cfg, maps)}
+    if value:
+        res["engine_over_port"] = value / v
     return res
 
 
@@ -1061,6 +1099,10 @@ def main():
                 result["multi_feature"] = multi_feature_figures(fc, util, np, torch, dev, max(3, min(args.steps, 10)))
             except Exception as e:
                 result["multi_feature"] = {"error": repr(e)}
+        try:        # the same GPU's vendor FFT library running the reference's loop: a baseline beside cpu_baseline, never `value`
+            result["vendor_fft_baseline"] = vendor_fft_figures(util, np, torch, dev, value=result["value"])
+        except Exception as e:
+            result["vendor_fft_baseline"] = {"error": repr(e)}
     if rank == 0:
         # RCCL prints a version banner through C stdio, which would otherwise be flushed after
         # Python's output at exit: flush it first so that the JSON line is the LAST line of stdout
