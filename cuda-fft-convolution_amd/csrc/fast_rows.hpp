@@ -33,17 +33,25 @@ template <int L_, int R1_, int R2_, int R3_, int NT_, int RPW_ = 1>
 struct RowCfg {
     static constexpr int L = L_, R1 = R1_, R2 = R2_, R3 = R3_, NT = NT_, RPW = RPW_;
     static constexpr int m1 = L / R1;        // stage-1 sub-length (= R2*R3)
+    // LDS image of a row: the R1 stage-1 blocks lie S1 >= m1 cells apart.  The stage-2 accesses of a wave's lanes run over b (R3
+    // consecutive cells) and then jump to the next block: with S1 = m1 that jump is a multiple of all 32 banks for most lengths
+    // (528 cells at 4224 = 1056 dwords) and the lanes on both sides of it collide -- a quarter of the kernel's LDS cycles were
+    // bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05s_*).  S1 = R3 (mod 16) continues the bank
+    // sequence across the jump.  FC_ROWS_NO_BLOCK_PAD = 1 (diagnostic builds) restores S1 = m1.
+    static constexpr int PAD1 = FC_ROWS_NO_BLOCK_PAD ? 0 : ((R3 - m1 % 16) % 16 + 16) % 16;
+    static constexpr int S1 = m1 + PAD1;     // LDS distance of two stage-1 blocks
+    static constexpr int LR = R1 * S1;       // LDS cells of one row
     static constexpr int NB1 = m1;           // butterflies per stage and row
     static constexpr int NB2 = R1 * R3;
     static constexpr int NB3 = R1 * R2;
     static constexpr int RND1 = (RPW * NB1 + NT - 1) / NT;
     static constexpr int RND2 = (RPW * NB2 + NT - 1) / NT;
     static constexpr int T2N = fc_tw2_pitch(R2) * R3;  // stage-2 twiddle image in LDS (fc_common.hpp: fc_tw2_fill)
-    static constexpr int LDS_ELEMS = RPW * L + T2N;  // c32
+    static constexpr int LDS_ELEMS = RPW * LR + T2N;  // c32
     static_assert(R1 * R2 * R3 == L, "radices must multiply to L");
     static_assert(RPW * NB3 <= NT, "one stage-3 butterfly per thread");
     static_assert(R3 % 2 == 0, "register-order layout pairs stage-3 elements");
-    static_assert((R3 * 8) % 16 == 0, "stage-3 runs must be 16-byte aligned");
+    static_assert((R3 * 8) % 16 == 0 && (S1 * 8) % 16 == 0, "stage-3 runs must be 16-byte aligned");
 };
 
 // position of element (q, a) of the register-order layout

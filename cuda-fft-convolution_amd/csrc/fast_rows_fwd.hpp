@@ -25,9 +25,9 @@ struct RowFwdState {};
 
 template <class C, class Ctx>
 FC_HD void fast_rows_fwd_body(Ctx& ctx, c32* lds, const FastRowsFwdArgs& g, int group, int rows) {
-    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
+    constexpr int R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW, S1 = C::S1, LR = C::LR;
     using State = RowFwdState;
-    c32* tw2 = lds + RPW * L;
+    c32* tw2 = lds + RPW * LR;
     const int row0 = group * RPW;
 
     // stage 1 (radix R1 over inputs m1 apart, decimation in frequency): block c of the row gets
@@ -50,11 +50,11 @@ FC_HD void fast_rows_fwd_body(Ctx& ctx, c32* lds, const FastRowsFwdArgs& g, int 
                 Dft<R1, -1>::run(v);
                 c32 p[R1];
                 power_chain<R1>(g.tw1[j], p);
-                c32* buf = lds + rr * L;
+                c32* buf = lds + rr * LR;
                 buf[j] = v[0];
                 static_for<1, R1>([&](auto c_) {
                     constexpr int c = decltype(c_)::value;
-                    buf[c * m1 + j] = cmul(v[c], p[c]);
+                    buf[c * S1 + j] = cmul(v[c], p[c]);
                 });
             }
         });
@@ -68,7 +68,7 @@ FC_HD void fast_rows_fwd_body(Ctx& ctx, c32* lds, const FastRowsFwdArgs& g, int 
             const int rr = u / C::NB2, w = u - rr * C::NB2;
             if (rr < RPW && row0 + rr < rows) {
                 const int c1 = w / R3, b = w - c1 * R3;
-                c32* p = lds + rr * L + c1 * m1 + b;
+                c32* p = lds + rr * LR + c1 * S1 + b;
                 c32 v[R2];
                 static_for<0, R2>([&](auto a_) {
                     constexpr int a = decltype(a_)::value;
@@ -90,7 +90,7 @@ FC_HD void fast_rows_fwd_body(Ctx& ctx, c32* lds, const FastRowsFwdArgs& g, int 
         const int rr = t / C::NB3, q = t - rr * C::NB3;
         const int row = row0 + rr;
         if (rr < RPW && row < rows) {
-            const c32* p = lds + rr * L + q * R3;
+            const c32* p = lds + rr * LR + (q / R2) * S1 + (q % R2) * R3;
             c32 v[R3];
             static_for<0, R3 / 2>([&](auto h_) {
                 constexpr int h = decltype(h_)::value;

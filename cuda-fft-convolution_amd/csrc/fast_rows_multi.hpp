@@ -43,10 +43,10 @@ inline bool fast_rows_multi_linear(const FastRowsArgs& g, int L, int m1) {
 
 template <class C, int NZ2, bool LINEAR, bool MULTIF = false, class Ctx>
 FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int group, int kernel0, int nk, int rows) {
-    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW;
+    constexpr int L = C::L, R1 = C::R1, R2 = C::R2, R3 = C::R3, NT = C::NT, m1 = C::m1, RPW = C::RPW, S1 = C::S1, LR = C::LR;
     using State = RowMultiState<C, MULTIF>;
     const int nF = MULTIF ? g.F : 1;
-    c32* tw2 = lds + RPW * L;
+    c32* tw2 = lds + RPW * LR;
     const int kw = g.kw;
     const int row0 = group * RPW;
     const bool tiled = g.y_row_of != nullptr;
@@ -113,13 +113,13 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 if constexpr (MULTIF) FC_OPAQUE(u);
                 const int rr = u / C::NB1, j = u - rr * C::NB1;
                 if (rr < RPW && j < kw) {
-                    c32* buf = lds + rr * L;
+                    c32* buf = lds + rr * LR;
                     c32 p[R1];
                     power_chain<R1>(st.w1[r], p);
                     buf[j] = st.x[r];
                     static_for<1, R1>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;
-                        buf[c * m1 + j] = cmul(st.x[r], p[c]);
+                        buf[c * S1 + j] = cmul(st.x[r], p[c]);
                     });
                 }
             });
@@ -139,7 +139,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 const int rr = u / C::NB2, w = u - rr * C::NB2;
                 if (rr < RPW) {
                     const int c1 = w / R3, b = w - c1 * R3;
-                    c32* p = lds + rr * L + c1 * m1 + b;
+                    c32* p = lds + rr * LR + c1 * S1 + b;
                     c32 v[R2];
                     static_for<0, R2>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
@@ -187,7 +187,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         static_for<2 * (0), 2 * (S_EARLY)>([&](auto a_) { st.s[decltype(a_)::value] = mk(0.f, 0.f); });
                     }
                 }
-                c32* p = lds + rr * L + q * R3;
+                c32* p = lds + rr * LR + (q / R2) * S1 + (q % R2) * R3;     // run c of stage-1 block c1: q = c1 * R2 + c
                 c32 v[R3];
                 static_for<0, R3 / 2>([&](auto h_) {
                     constexpr int h = decltype(h_)::value;
@@ -271,7 +271,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 const int rr = u / C::NB2, w = u - rr * C::NB2;
                 if (rr < RPW) {
                     const int c1 = w / R3, b = w - c1 * R3;
-                    c32* p = lds + rr * L + c1 * m1 + b;
+                    c32* p = lds + rr * LR + c1 * S1 + b;
                     c32 v[R2];
                     v[0] = p[0];
                     fc_tw2_each<R2>(tw2, b, [&](auto c_, c32 w) {
@@ -313,7 +313,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                     FC_OPAQUE(u);
                     const int rr = u / C::NB1, j = u - rr * C::NB1;
                     if (rr < RPW && row0 + rr < rows) {
-                        const c32* buf = lds + rr * L;
+                        const c32* buf = lds + rr * LR;
                         c32 p[R1];
                         c32 v[R1];
                         if constexpr (FC_ROWSM_DBG & 1) {
@@ -324,7 +324,7 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         v[0] = buf[j];
                         static_for<1, R1>([&](auto c_) {
                             constexpr int c = decltype(c_)::value;
-                            v[c] = cmulc(buf[c * m1 + j], p[c]);
+                            v[c] = cmulc(buf[c * S1 + j], p[c]);
                         });
                         Dft<R1, +1>::run(v);
                         }
@@ -350,11 +350,11 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                             });
                         }
                         if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read
-                            c32* wbuf = lds + rr * L;
+                            c32* wbuf = lds + rr * LR;
                             wbuf[j] = st.x[r];
                             static_for<1, R1>([&](auto c_) {
                                 constexpr int c = decltype(c_)::value;
-                                wbuf[c * m1 + j] = cmul(st.x[r], p[c]);
+                                wbuf[c * S1 + j] = cmul(st.x[r], p[c]);
                             });
                         }
                     }
@@ -368,14 +368,14 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                 const int rr = u / C::NB1, j = u - rr * C::NB1;
                 const int row = row0 + rr;
                 if (rr < RPW && row < rows) {
-                    const c32* buf = lds + rr * L;
+                    const c32* buf = lds + rr * LR;
                     c32 p[R1];
                     power_chain<R1>(st.w1[r], p);
                     c32 v[R1];
                     v[0] = buf[j];
                     static_for<1, R1>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;
-                        v[c] = cmulc(buf[c * m1 + j], p[c]);
+                        v[c] = cmulc(buf[c * S1 + j], p[c]);
                     });
                     Dft<R1, +1>::run(v);
                     c32* yrow = ybase + st.yoff[r];
@@ -388,11 +388,11 @@ FC_HD void fast_rows_multi_body(Ctx& ctx, c32* lds, const FastRowsArgs& g, int g
                         }
                     });
                     if (FOLD && m + 1 < nk && j < kw) {   // forward stage 1 of the next map into the cells just read
-                        c32* wbuf = lds + rr * L;
+                        c32* wbuf = lds + rr * LR;
                         wbuf[j] = st.x[r];
                         static_for<1, R1>([&](auto c_) {
                             constexpr int c = decltype(c_)::value;
-                            wbuf[c * m1 + j] = cmul(st.x[r], p[c]);
+                            wbuf[c * S1 + j] = cmul(st.x[r], p[c]);
                         });
                     }
                 }

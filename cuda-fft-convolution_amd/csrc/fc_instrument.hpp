@@ -9,7 +9,7 @@
 #if !defined(FC_INSTRUMENT)
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
-    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY)
+    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_NO_BLOCK_PAD)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -40,6 +40,9 @@
 // ---- spectral-row kernels (fast_rows.hpp, fast_rows_multi.hpp)
 #ifndef FC_NT_SLOADS
 #define FC_NT_SLOADS 0           // 1: streaming loads for the image-spectrum rows
+#endif
+#ifndef FC_ROWS_NO_BLOCK_PAD
+#define FC_ROWS_NO_BLOCK_PAD 0   // 1: the stage-1 blocks of a row m1 cells apart in LDS (no padding against the stage-2 bank conflicts; A/B)
 #endif
 #ifndef FC_ROWS_NO_FOLD
 #define FC_ROWS_NO_FOLD 0        // 1: forward stage 1 as a phase of its own for every map
