@@ -20,12 +20,62 @@
 
 namespace fc {
 
+// LDS image of a column: the R1 stage-1 blocks of m1 = R2 * R3 cells lie S1 = m1 + pad cells apart (row kernels: RowCfg::S1,
+// fast_rows.hpp).  m1 cells are a multiple of all banks for most lengths (2112 = 6.16.22: 352 cells = 704 dwords), so the lanes
+// of a stage-2 access on the two sides of a block boundary -- b runs over R3 cells, then the next block -- collide, and so do
+// the landing stores of consecutive bin pairs (their positions differ in the FIRST digit: m1 cells apart).  With S1 = R3 (mod
+// 32 cells) the bank sequence continues across the boundary.  Stage 3 reads 16-byte slots at a stride of R3 / 2 slots per run;
+// the pad shifts the runs of every other block by pad / 2 slots against their neighbours in the same 16-lane access group, so
+// the threads of odd blocks take their runs rotated by `rot` (the assignment of runs to threads is free: a stage-3 butterfly
+// works in place).  Both per configuration from tools/lds_bank_model.py, which counts the LDS cycles of every access of a tile
+// with the bank rules of the hardware (SQ_LDS_BANK_CONFLICT of the cfg3 kernel: model 27.4 %, measured 29.2 % of the LDS
+// cycles without the pad; model 6 % with it).  FC_COLS_NO_BLOCK_PAD = 1 (diagnostic builds): the dense image.
+// X(M, R1, R2, R3, T, pad, rot): from `tools/lds_bank_model.py --search` (it lists a pad for every configuration of fast_paths.hpp:
+// 7-35 % fewer modelled LDS cycles per tile).  Only the configurations whose output kernel MEASURED faster on the padded image are
+// listed -- the kernel is bound by its memory stream, not by the LDS array, and a larger image is not free (same-box A/Bs of 4-6
+// fresh processes per variant, profiles/r05u_cols_block_padding_all_configs.txt): M = 2112 (cfg3 / cfg4) -0.6 %, 1536 -1 %, 1280
+// -0.5 ... -1 %, 576 -1.7 ... -2.7 %, 384 -3 %; within +-0.5 % at M = 144, 288, 672, 880, 960, 1056, 1760, 1920, 2304, 2816, 3072, 3840;
+// SLOWER at M = 768 (+2 %), 1152 (+1 %), 1408 (+2.4 %).  A configuration that is not listed runs on the dense image (pad 0, rot 0).
+#define FC_COL_LAYOUTS(X)      \
+    X(2112, 6, 16, 22, 8, 22, 15) /* LDS cycles per tile 7896 -> 6102 (SQ_LDS_IDX_ACTIVE -17 %, SQ_LDS_BANK_CONFLICT -64 %) */ \
+    X(1536, 8, 16, 12, 8, 12, 0)  /* 7801 -> 5565 */ \
+    X(1280, 8, 16, 10, 8, 10, 15) /* 5609 -> 3687 */ \
+    X(576, 6, 8, 12, 16, 14, 0)   /* 6739 -> 5355 */ \
+    X(384, 4, 8, 12, 16, 6, 0)    /* 4567 -> 3631 */
+
+struct ColLayout { int pad, rot; };
+constexpr ColLayout col_layout(int M, int R1, int R2, int R3, int T) {
+    if (FC_COLS_NO_BLOCK_PAD) return {0, 0};
+#define FC_X(MM, A, B, C, TT, PP, RR) \
+    if (M == MM && R1 == A && R2 == B && R3 == C && T == TT) return {PP, RR};
+    FC_COL_LAYOUTS(FC_X)
+#undef FC_X
+    return {0, 0};
+}
+
 template <int M_, int R1_, int R2_, int R3_, int T_, int NT_>
 struct ColCfg {
     static constexpr int M = M_, R1 = R1_, R2 = R2_, R3 = R3_, T = T_, NT = NT_;
     static constexpr int m1 = M / R1;            // stage-1 sub-length (= R2*R3)
     static constexpr int NB1 = m1, NB2 = R1 * R3, NB3 = R1 * R2;  // butterflies per column
-    static constexpr int LP = ((M + 1 + 13) / 16) * 16 + 2;      // column pitch: >= M+1, == 2 mod 16
+    static constexpr int PAD = col_layout(M_, R1_, R2_, R3_, T_).pad, ROT = col_layout(M_, R1_, R2_, R3_, T_).rot;
+    static constexpr int S1 = m1 + PAD;          // LDS distance of two stage-1 blocks
+    static constexpr int MP = R1 * S1;           // cells of a column's image; the Nyquist slot sits at MP
+    static constexpr int LP = ((MP + 1 + 13) / 16) * 16 + 2;     // column pitch: >= MP+1, == 2 mod 16
+    // LDS cell of position p of the dense sequence (p = M: the Nyquist slot)
+    static FC_HD constexpr int cell(int p) { return PAD ? p + (p / m1) * PAD : p; }
+    // start of stage-3 run q (q = block * R2 + c: cells [c * R3, (c + 1) * R3) of block `block`), as thread q takes it
+    static FC_HD constexpr int run_of_thread(int q) {
+        if constexpr (PAD == 0 && ROT == 0) return q * R3;
+        else {
+            const int blk = q / R2;
+            int c = q - blk * R2;
+            if constexpr (ROT != 0) {
+                if (blk & 1) c = c + ROT >= R2 ? c + ROT - R2 : c + ROT;
+            }
+            return blk * S1 + c * R3;
+        }
+    }
     static constexpr int UPT = (M * T) / (2 * NT);               // 16-byte gather units per thread
     static constexpr int NPAIR = M / 2 - 1;                      // ordinary pairs per column
     static constexpr int RNDP = (NPAIR * T + NT - 1) / NT;
@@ -49,7 +99,9 @@ struct ColCfg {
     static_assert(NB3 * T == NT, "one stage-3 butterfly per thread");
     static_assert((M * T) % (2 * NT) == 0, "gather units must divide evenly");
     static_assert(R3 % 2 == 0, "stage-3 runs are read 16 bytes at a time");
-    static_assert(LP >= M + 1 && LP % 16 == 2, "column pitch");
+    static_assert(LP >= MP + 1 && LP % 16 == 2, "column pitch");
+    static_assert(PAD % 2 == 0 && PAD >= 0 && ROT >= 0 && ROT < R2, "stage-3 runs must stay 16-byte aligned");
+    static_assert(MP < 65536, "pair positions are packed in 16 bits");
     static_assert(LDS_ELEMS * 8 <= 160 * 1024, "LDS budget");
 };
 
@@ -173,6 +225,14 @@ FC_HD int pair_of_unit(int u) {
         if (u < FULL) {
             const int sb = u / SB, i = u - sb * SB;
             return sb * SB + (i & 3) * C::NB3 + (i >> 2);
+        }
+        // what is left of a superblock: pairs of pairs NB3 apart; with the padded image (S1 = R3 mod 32, R3 = 2 mod 4) the four
+        // pairs k, k + NB3, k + 1, k + 1 + NB3 of a group land on cells 0, 1, S1, S1 + 1 = four distinct residues mod 4 beside
+        // the column pairs' 0, 4, 8, 12
+        constexpr int SB2 = 2 * C::NB3, FULL2 = FULL + (C::PAD ? ((NP - FULL) / SB2) * SB2 : 0);
+        if (u < FULL2) {
+            const int sb = (u - FULL) / SB2, i = u - FULL - sb * SB2;
+            return FULL + sb * SB2 + (i & 1) * C::NB3 + (i >> 1);
         }
         return u;
     } else {
@@ -298,7 +358,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 if constexpr (SLICED) mine = mine && 2 * (e % T2) >= c_lo && 2 * (e % T2) < c_hi;
                 if (mine) {
                     const int k = pair_of_unit<C>(e / T2), t2 = e % T2;
-                    const unsigned pp = ppos[k];
+                    const unsigned pp = ppos[e / T2];     // the table is in unit order here (prologue)
                     const int pa = (int)(pp & 0xffffu), pb = (int)(pp >> 16);
                     c32* z0 = lds + (2 * t2) * LP;
                     c32* z1 = z0 + LP;
@@ -341,13 +401,13 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
             constexpr int r = decltype(r_)::value;
             const int e = t + NT * r;
             const int t2 = e % T2;
-            const int p = e / T2;
+            const int p = C::cell(e / T2);
             lds[(2 * t2) * LP + p] = st.pre[r].a;
             lds[(2 * t2 + 1) * LP + p] = st.pre[r].b;
         });
         if (t < T2) {
-            lds[(2 * t) * LP + M] = st.pre_ny.a;
-            lds[(2 * t + 1) * LP + M] = st.pre_ny.b;
+            lds[(2 * t) * LP + C::MP] = st.pre_ny.a;
+            lds[(2 * t + 1) * LP + C::MP] = st.pre_ny.b;
         }
         }
     };
@@ -356,12 +416,21 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
     ctx.phase([&](int t, State& st) {
         for (int i = t; i < C::T2N; i += NT) tw2[i] = g.tw2[i];
         for (int i = t; i < m1; i += NT) tw1[i] = g.tw1[i];
+        // pair positions as LDS cells; tiled intermediate: in the order the landing takes them (unit u handles pair
+        // pair_of_unit(u): consecutive lanes then read consecutive dwords -- in pair order the pairs of an access group are
+        // NB3 apart, a multiple of the 32 banks)
         for (int i = t; i < C::NPE; i += NT) {
-                const PairEntry e = g.pairs[i];
-                ppos[i] = (unsigned)e.a | ((unsigned)e.b << 16);
-                if ((i & 31) == 0) wh[i >> 5] = e.w;      // w^(32*hi)
-                if (i < 32) wl[i] = e.w;                  // w^lo  (entry 0 holds w^0 = 1)
+                const PairEntry e = g.pairs[PLAND ? pair_of_unit<C>(i) : i];
+                ppos[i] = (unsigned)C::cell(e.a) | ((unsigned)C::cell(e.b) << 16);
+                if constexpr (!PLAND) {
+                    if ((i & 31) == 0) wh[i >> 5] = e.w;      // w^(32*hi)
+                    if (i < 32) wl[i] = e.w;                  // w^lo  (entry 0 holds w^0 = 1)
+                }
             }
+        if constexpr (PLAND) {
+            for (int i = t; i < C::NWH; i += NT) wh[i] = g.pairs[32 * i].w;
+            if (t < 32) wl[t] = g.pairs[t].w;
+        }
         if constexpr (!PLAND)
         static_for<0, C::UPT>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
@@ -431,7 +500,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
         ctx.template phase_dbg<(FC_COLS_DBG & 2) != 0>([&](int t, State&) {
             const int col = t / C::NB3, q = t % C::NB3;
             if constexpr (SLICED) { if (col < cur_lo || col >= cur_hi) return; }
-            c32* p = lds + col * LP + q * R3;
+            c32* p = lds + col * LP + C::run_of_thread(q);
             c32 v[R3];
             static_for<0, R3 / 2>([&](auto h_) {
                 constexpr int h = decltype(h_)::value;
@@ -466,7 +535,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                 if (mine2) {
                     const int col = idx / C::NB2, u = idx % C::NB2;
                     const int c1 = u / R3, b = u % R3;
-                    c32* p = lds + col * LP + c1 * m1 + b;
+                    c32* p = lds + col * LP + c1 * C::S1 + b;
                     c32 v[R2];
                     v[0] = p[0];
                     static_for<1, R2>([&](auto c_) {
@@ -519,7 +588,7 @@ FC_HD void fast_cols_body(Ctx& ctx, c32* lds, const FastColsArgs& g, int wg, int
                     v[0] = p[0];
                     static_for<1, R1>([&](auto c_) {
                         constexpr int c = decltype(c_)::value;
-                        v[c] = cmulc(p[c * m1], pw[c]);
+                        v[c] = cmulc(p[c * C::S1], pw[c]);
                     });
                     Dft<R1, +1>::run(v);
                     c32* o = reinterpret_cast<c32*>(out + (size_t)(w0 + col) * g.out_pitch);

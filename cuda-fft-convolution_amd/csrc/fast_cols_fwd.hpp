@@ -62,7 +62,7 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
         for (int i = t; i < m1; i += NT) tw1[i] = g.tw1[i];
         for (int i = t; i < C::NPE; i += NT) {
             const PairEntry e = g.pairs[i];
-            ppos[i] = (unsigned)e.a | ((unsigned)e.b << 16);
+            ppos[i] = (unsigned)C::cell(e.a) | ((unsigned)C::cell(e.b) << 16);   // LDS cells (fast_cols.hpp: ColCfg::cell)
             if ((i & 31) == 0) wh[i >> 5] = e.w;
             if (i < 32) wl[i] = e.w;
         }
@@ -103,7 +103,7 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
                         q[0] = z;
                         static_for<1, R1>([&](auto c_) {
                             constexpr int c = decltype(c_)::value;
-                            q[c * m1] = cmul(z, p[c]);
+                            q[c * C::S1] = cmul(z, p[c]);
                         });
                     }
                 }
@@ -130,7 +130,7 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
                         q[0] = v[0];
                         static_for<1, R1>([&](auto c_) {
                             constexpr int c = decltype(c_)::value;
-                            q[c * m1] = cmul(v[c], p[c]);
+                            q[c * C::S1] = cmul(v[c], p[c]);
                         });
                     }
                 }
@@ -145,7 +145,7 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
                 if (idx < C::NB2 * T) {
                     const int col = idx / C::NB2, u = idx % C::NB2;
                     const int c1 = u / R3, b = u % R3;
-                    c32* p = lds + col * LP + c1 * m1 + b;
+                    c32* p = lds + col * LP + c1 * C::S1 + b;
                     c32 v[R2];
                     static_for<0, R2>([&](auto a_) {
                         constexpr int a = decltype(a_)::value;
@@ -170,7 +170,7 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
         // F3: stage 3 (radix R3 on contiguous runs), one butterfly per thread
         ctx.phase([&](int t, State&) {
             const int col = t / C::NB3, q = t % C::NB3;
-            c32* p = lds + col * LP + q * R3;
+            c32* p = lds + col * LP + C::run_of_thread(q);
             c32 v[R3];
             static_for<0, R3 / 2>([&](auto h_) {
                 constexpr int h = decltype(h_)::value;
@@ -227,7 +227,7 @@ FC_HD void fast_cols_fwd_body(Ctx& ctx, c32* lds, const FastColsFwdArgs& g, int 
         ctx.phase([&](int t, State&) {
             for (int idx = t; idx < (M + 1) * T; idx += NT) {
                 const int p = idx / T, col = idx % T;
-                if (c0 + col < g.ncols) out[(size_t)p * g.out_pitch + c0 + col] = lds[col * LP + p];
+                if (c0 + col < g.ncols) out[(size_t)p * g.out_pitch + c0 + col] = lds[col * LP + C::cell(p)];
             }
         });
         if (dyn) {

@@ -9,7 +9,8 @@
 #if !defined(FC_INSTRUMENT)
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
-    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_NO_BLOCK_PAD)
+    defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_NO_BLOCK_PAD) || \
+    defined(FC_COLS_NO_BLOCK_PAD)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -33,6 +34,9 @@
 #ifndef FC_COLS_PAIR_TRANSPOSE
 #define FC_COLS_PAIR_TRANSPOSE 2 // landing order of the bin pairs (fast_cols.hpp: pair_of_unit): 0 consecutive, 1 permuted for 4-column tiles,
 #endif                           // 2 also for the 8-column configurations whose consecutive pairs share a bank
+#ifndef FC_COLS_NO_BLOCK_PAD
+#define FC_COLS_NO_BLOCK_PAD 0   // 1: the dense LDS image of a column (no pad between the stage-1 blocks, no run rotation; fast_cols.hpp: col_layout; A/B)
+#endif
 #ifndef FC_COLS_NO_PREWAIT
 #define FC_COLS_NO_PREWAIT 0     // 1: without the vmcnt(0) ahead of the store burst
 #endif

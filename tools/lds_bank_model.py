@@ -12,7 +12,7 @@ cycle per group when conflict-free; every further distinct address on a busy ban
 Prints cycles and conflict cycles per phase for a configuration, for block paddings PAD (stage-1 blocks S1 = m1 + PAD cells
 apart) and column pitches, so that a layout can be chosen before it is built.
 
-usage: lds_bank_model.py M R1 R2 R3 T NT [PAD ...]
+usage: lds_bank_model.py M R1 R2 R3 T NT [PAD ...]   |   lds_bank_model.py --search
 """
 import sys
 
@@ -75,7 +75,7 @@ def pair_of_unit(u, M, R1, R2, R3, T, transpose=2, two_level=False):
     return u
 
 
-def model(M, R1, R2, R3, T, NT, PAD, pitch_mod=(16, 2), transpose=2, verbose=True, rot=0, by_unit=False, two_level=False):
+def model(M, R1, R2, R3, T, NT, PAD, pitch_mod=(16, 2), transpose=2, verbose=True, rot=0, by_unit=False, two_level=False, parts=("landing", "s3", "s2", "s1"), rot_all=False):
     m1 = M // R1
     S1 = m1 + PAD
     MP = R1 * S1                      # padded column image without the Nyquist slot
@@ -102,7 +102,7 @@ def model(M, R1, R2, R3, T, NT, PAD, pitch_mod=(16, 2), transpose=2, verbose=Tru
     # landing (C5)
     T2 = T // 2
     NPU = NPE * T2
-    for r_ in range((NPU + NT - 1) // NT):
+    for r_ in range((NPU + NT - 1) // NT if "landing" in parts else 0):
         ks, za, zb, z1a, z1b, whs, wls, pps = [], [], [], [], [], [], [], []
         for t in range(NT):
             e = t + NT * r_
@@ -130,19 +130,19 @@ def model(M, R1, R2, R3, T, NT, PAD, pitch_mod=(16, 2), transpose=2, verbose=Tru
             ta.access("landing: stores", "w64", lst)
 
     # C2: stage 3
-    for h in range(R3 // 2):
+    for h in range(R3 // 2 if "s3" in parts else 0):
         a = []
         for t in range(NT):
             col, qq = divmod(t, NB3)
             blk, c = divmod(qq, R2)
-            if rot and (blk & 1):
-                c = (c + rot) % R2
+            if rot and (rot_all or (blk & 1)):
+                c = (c + rot * (blk if rot_all else 1)) % R2
             a.append(D(col * LP + blk * S1 + c * R3 + 2 * h))
         ta.access("stage 3: reads", "r128", a)
         ta.access("stage 3: writes", "w128", a)
 
     # C3: stage 2
-    for r_ in range((NB2 * T + NT - 1) // NT):
+    for r_ in range((NB2 * T + NT - 1) // NT if "s2" in parts else 0):
         base, bs = [], []
         for t in range(NT):
             idx = t + NT * r_
@@ -161,7 +161,7 @@ def model(M, R1, R2, R3, T, NT, PAD, pitch_mod=(16, 2), transpose=2, verbose=Tru
             ta.access("stage 2: writes", "w64", [None if x is None else D(x + c * R3) for x in base])
 
     # C4: stage 1
-    for r_ in range((NB1 * T + NT - 1) // NT):
+    for r_ in range((NB1 * T + NT - 1) // NT if "s1" in parts else 0):
         base, js = [], []
         for t in range(NT):
             idx = t + NT * r_
@@ -187,7 +187,38 @@ def model(M, R1, R2, R3, T, NT, PAD, pitch_mod=(16, 2), transpose=2, verbose=Tru
     return tc, te, total * 8
 
 
+CONFIGS = """4224 8 24 22 4 768; 3840 8 24 20 4 768; 3520 10 16 22 4 640; 3072 8 32 12 4 1024; 2816 8 16 22 4 512; 2560 8 32 10 4 1024; 2304 8 16 18 8 1024;
+2112 6 16 22 8 768; 2080 8 13 20 8 832; 1920 8 12 20 8 768; 1760 5 16 22 8 640; 1680 6 20 14 8 960; 1536 8 16 12 8 1024; 1408 8 8 22 8 512; 1280 8 16 10 8 1024;
+1152 8 12 12 8 768; 1056 6 8 22 16 768; 960 6 8 20 16 768; 880 5 8 22 16 640; 768 8 8 12 16 1024; 672 6 8 14 16 768; 640 8 8 10 16 1024; 576 6 8 12 16 768;
+544 17 4 8 8 544; 480 6 8 10 16 768; 432 6 6 12 16 576; 384 4 8 12 16 512; 336 4 6 14 16 384; 288 4 6 12 16 384; 240 4 6 10 16 384; 192 4 8 6 16 512; 144 4 6 6 16 384"""
+
+
+def search_one(c):
+    """best (pad, rot) of one configuration: fewest modelled LDS cycles per tile among the paddings that fit 160 KiB"""
+    dense = model(*c, 0, verbose=False)
+    rows = []
+    for pad in range(0, 48, 2):
+        tc, te, b = model(*c, pad, verbose=False, by_unit=True, two_level=True, parts=("landing", "s2", "s1"))
+        if b > 160 * 1024:
+            break
+        t3, rot = min((model(*c, pad, verbose=False, rot=rot, parts=("s3",))[0], rot) for rot in range(c[2]))
+        rows.append((tc + t3, pad, rot, b))
+    return c, dense, min(rows)
+
+
+def search():
+    """--search: the FC_COL_LAYOUTS list of csrc/fast_cols.hpp (configurations: fast_paths.hpp FC_FAST_COL_CONFIGS)"""
+    from multiprocessing import Pool
+    cfgs = [tuple(int(x) for x in c.split()) for c in CONFIGS.replace("\n", " ").split(";")]
+    with Pool(8) as p:
+        for c, dense, (cyc, pad, rot, b) in p.imap(search_one, cfgs):
+            print("    X(%d, %d, %d, %d, %d, %d, %d) /* LDS cycles per tile %d -> %d, %d bytes */ \\" % (c[0], c[1], c[2], c[3], c[4], pad, rot, dense[0], cyc, b))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["--search"]:
+        search()
+        sys.exit(0)
     a = [int(x) for x in sys.argv[1:]]
     M, R1, R2, R3, T, NT = a[:6]
     pads = a[6:] or [0]
