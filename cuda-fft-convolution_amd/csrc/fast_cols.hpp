@@ -220,7 +220,7 @@ FC_HD int pair_of_unit(int u) {
         return ((u | 63) < NP) ? ((u & ~63) | ((u & 7) << 3) | ((u >> 3) & 7)) : u;
     } else if constexpr (C::T == 8 && FC_COLS_PAIR_TRANSPOSE >= 2 && (2 * C::m1) % 32 == 0) {
         // 8-column tiles: 4 pairs x 4 column pairs per access group; where consecutive pairs collide on one bank (m1 cells a
-        // multiple of the 32 banks: M = 2304, 1920, 1536, 1408, 1280 -- not cfg3's M = 2112) the 4 pairs of a group are taken NB3 apart
+        // multiple of the 32 banks: M = 2304, 2112 as 6.16.22, 1920, 1536, 1408, 1280) the 4 pairs of a group are taken NB3 apart
         constexpr int NP = C::M / 2 + 1, SB = 4 * C::NB3, FULL = (NP / SB) * SB;
         if (u < FULL) {
             const int sb = u / SB, i = u - sb * SB;
