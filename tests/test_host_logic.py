@@ -355,6 +355,31 @@ def _resource_reports():
     return out
 
 
+def test_lds_bank_model_reproduces_the_documented_layout_of_cfg3():
+    """tools/lds_bank_model.py chose the padded LDS images of the output kernel (csrc/fast_cols.hpp: FC_COL_LAYOUTS); the
+    figures the kernel's comments and DESIGN.md 4 quote for cfg3's configuration (dense: 7 896 LDS cycles per tile, 2 160 of
+    them conflicts = 27.4 %, the counters say 29.2 %; padded: 6 102) must keep coming out of it, and every listed layout
+    must fit the LDS and be what the header lists"""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(util.ROOT, "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.model(2112, 6, 16, 22, 8, 768, 0, verbose=False)[:2] == (7896, 2160)
+    assert m.model(2112, 6, 16, 22, 8, 768, 22, verbose=False, rot=15, by_unit=True, two_level=True)[:2] == (6102, 366)
+    hdr = open(os.path.join(util.ROOT, "cuda-fft-convolution_amd", "csrc", "fast_cols.hpp")).read()
+    listed = re.findall(r"^    X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", hdr, flags=re.M)
+    assert len(listed) >= 5
+    configs = {tuple(int(x) for x in c.split()[:5]): int(c.split()[5]) for c in m.CONFIGS.replace("\n", " ").split(";")}
+    for ent in listed:
+        M, R1, R2, R3, T, pad, rot = (int(x) for x in ent)
+        assert (M, R1, R2, R3, T) in configs, ent                 # a configuration of fast_paths.hpp
+        NT = configs[(M, R1, R2, R3, T)]
+        dense = m.model(M, R1, R2, R3, T, NT, 0, verbose=False)
+        padded = m.model(M, R1, R2, R3, T, NT, pad, verbose=False, rot=rot, by_unit=True, two_level=True)
+        assert padded[2] <= 160 * 1024 and padded[0] < dense[0], (ent, dense, padded)
+
+
 def test_hot_kernels_do_not_spill():
     """Register allocation is part of the product: a spilled register in a hot loop costs the output kernel 20 %
      and scratch traffic shares the in-order memory counter with the prefetches.  Asserted on the build's
