@@ -10,7 +10,7 @@
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
     defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_NO_BLOCK_PAD) || \
-    defined(FC_COLS_NO_BLOCK_PAD)
+    defined(FC_COLS_NO_BLOCK_PAD) || defined(FC_ROWS_STAGGER_TICKS)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -48,6 +48,9 @@
 #ifndef FC_ROWS_NO_BLOCK_PAD
 #define FC_ROWS_NO_BLOCK_PAD 0   // 1: the stage-1 blocks of a row m1 cells apart in LDS (no padding against the stage-2 bank conflicts; A/B)
 #endif
+#ifndef FC_ROWS_STAGGER_TICKS
+#define FC_ROWS_STAGGER_TICKS 0  // > 0 (experiment, needs plan option timeline_ptr = a zeroed device buffer of 4096 ints): the k-th workgroup of the launch's first round
+#endif                           //   to arrive on its CU (a counter per CU, keyed by XCC_ID and HW_ID) waits k x this many 10-ns ticks before it starts
 #ifndef FC_ROWS_NO_FOLD
 #define FC_ROWS_NO_FOLD 0        // 1: forward stage 1 as a phase of its own for every map
 #endif
@@ -83,7 +86,8 @@
 #define FC_COLS_STAMP(slot) ((void)0)
 #endif
 #if FC_ROWS_TIMELINE && defined(__HIP_DEVICE_COMPILE__)
-#define FC_ROWS_STAMP(slot) do { if (group == FC_ROWS_TIMELINE_WG && kernel0 == 0 && threadIdx.x == 0 && g.timeline && m < 16) g.timeline[m * 8 + (slot)] = wall_clock64(); } while (0)
+// (slot 0 of a map also leaves the shader-cycle counter in slot 6: delta s_memtime / delta wall clock x 100 MHz = the clock the workgroup ran at)
+#define FC_ROWS_STAMP(slot) do { if (group == FC_ROWS_TIMELINE_WG && kernel0 == 0 && threadIdx.x == 0 && g.timeline && m < 16) { g.timeline[m * 8 + (slot)] = wall_clock64(); if ((slot) == 0) g.timeline[m * 8 + 6] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define FC_ROWS_STAMP(slot) ((void)0)
 #endif

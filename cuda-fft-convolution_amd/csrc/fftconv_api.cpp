@@ -875,7 +875,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
     }
     if (!strcmp(name, "profile_kinds")) { plan->profile_mask = value <= 0 ? ~0u : (unsigned)value; return 0; }
     if (!strcmp(name, "rows_group")) { plan->g.rows_group = value <= 0 ? -1 : (int)value; return 0; }
-#if FC_ROWS_TIMELINE || FC_COLS_TIMELINE
+#if FC_ROWS_TIMELINE || FC_COLS_TIMELINE || FC_ROWS_STAGGER_TICKS
     // diagnostic builds only (tools/rows_timeline.py, tools/cols_timeline.py): device buffer one workgroup stamps
     if (!strcmp(name, "timeline_ptr")) { plan->d.timeline = reinterpret_cast<unsigned long long*>((uintptr_t)value); return 0; }
 #endif

@@ -13,14 +13,16 @@ ker = torch.rand((n, 1, kw, kh), dtype=torch.float32, device="cuda")
 plan = fc.Plan(H, W, 1, kh, kw, stream=torch.cuda.current_stream().cuda_stream)
 out = torch.empty((n, plan.info.fft_w, plan.info.fft_h), dtype=torch.float32, device="cuda")
 plan.set_option("timeline_ptr", dbg.data_ptr())   # exists in FC_*_TIMELINE builds only
-for rep in range(3):
+for rep in range(int(os.environ.get("STEPS", "3"))):      # STEPS=80: the stamped launch is one of a warm process (clocks settled)
     plan.set_image_device(img.data_ptr())
     plan.convolve_packed_device(n, ker.data_ptr(), kh, kw, out.data_ptr())
 torch.cuda.synchronize()
-t = dbg.cpu().numpy().reshape(16, 8).astype(np.float64) / 100.0
+raw = dbg.cpu().numpy().reshape(16, 8)
+t = raw.astype(np.float64) / 100.0
 names = ["P1 fwd stage 1", "P2 fwd stage 2", "P3 stage 3 x S", "P4 inv stage 2", "P5 inv stage 1 + stores"]
 print("map    " + "  ".join("%24s" % s for s in names) + "   total")
 for m in range(1, 15):
     d = [t[m, k + 1] - t[m, k] for k in range(5)]
-    print("%4d   " % m + "  ".join("%24.2f" % x for x in d) + "   %.2f" % (t[m + 1, 0] - t[m, 0]))
+    mhz = (float(raw[m + 1, 6] - raw[m, 6]) / max(1.0, float(raw[m + 1, 0] - raw[m, 0])) * 100.0) if raw[m, 6] else 0.0
+    print("%4d   " % m + "  ".join("%24.2f" % x for x in d) + "   %.2f" % (t[m + 1, 0] - t[m, 0]) + ("   shader clock %.0f MHz" % mhz if mhz else ""))
 plan.destroy()
