@@ -10,7 +10,7 @@
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
     defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_NO_BLOCK_PAD) || \
-    defined(FC_COLS_NO_BLOCK_PAD) || defined(FC_ROWS_STAGGER_TICKS)
+    defined(FC_COLS_NO_BLOCK_PAD) || defined(FC_ROWS_STAGGER_TICKS) || defined(FC_ROWS_STAGGER_RAMP)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -51,6 +51,9 @@
 #ifndef FC_ROWS_STAGGER_TICKS
 #define FC_ROWS_STAGGER_TICKS 0  // > 0 (experiment, needs plan option timeline_ptr = a zeroed device buffer of 4096 ints): the k-th workgroup of the launch's first round
 #endif                           //   to arrive on its CU (a counter per CU, keyed by XCC_ID and HW_ID) waits k x this many 10-ns ticks before it starts
+#ifndef FC_ROWS_STAGGER_RAMP
+#define FC_ROWS_STAGGER_RAMP 0   // with FC_ROWS_STAGGER_TICKS: 1 = workgroup b of the first round waits b / 1024 x TICKS (a chip-wide ramp) instead of its rank on its CU x TICKS
+#endif
 #ifndef FC_ROWS_NO_FOLD
 #define FC_ROWS_NO_FOLD 0        // 1: forward stage 1 as a phase of its own for every map
 #endif

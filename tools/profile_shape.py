@@ -19,7 +19,7 @@ with fc.Plan(H, W, F, K, K, options=opts) as p:
     if os.environ.get("DYN"): p.set_option("dynamic_tiles", int(os.environ["DYN"]))      # tile queue of the column kernels on / off (A/B)
     stagger = None
     if os.environ.get("STAGGER"):      # -DFC_ROWS_STAGGER_TICKS builds: the per-CU arrival counters (+ what each first-round workgroup saw)
-        stagger = torch.zeros(4096, dtype=torch.int32, device=dev)
+        stagger = torch.zeros(8192, dtype=torch.int32, device=dev)
         try: p.set_option("timeline_ptr", stagger.data_ptr())
         except Exception: stagger = None          # a library without the experiment
     out = torch.empty((n, i.fft_w, i.fft_h), dtype=torch.float32, device=dev)
@@ -41,7 +41,7 @@ with fc.Plan(H, W, F, K, K, options=opts) as p:
     if stagger is not None:
         import collections
         st = stagger.cpu().numpy()
-        keys, ks = st[2048::2], st[2049::2]
+        keys, ks = st[2560:4608:2], st[2561:4608:2]
         per_cu = collections.Counter(int(x) for x in keys)
         same = sum(1 for b in range(256) if len({int(keys[b + 256 * j]) for j in range(4)}) == 1)
         print("   stagger: %d CU keys among the first 1024 workgroups, workgroups per key %s; blocks b, b+256, b+512, b+768 on one CU for %d of 256 b; first keys %s; ranks of blocks 0..15: %s"

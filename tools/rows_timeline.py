@@ -4,7 +4,7 @@ per map of the walk: 0 start, 1 after P1, 2 after P2, 3 after P3, 4 after P4, 5 
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
-dbg = torch.zeros(16 * 8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4096, dtype=torch.int64, device="cuda")    # stamps [16][8]; behind them the counters of -DFC_ROWS_STAGGER_TICKS builds
 import util
 fc = util.load_package()
 H = W = 4096; kh = kw = 127; n = 64
@@ -17,7 +17,7 @@ for rep in range(int(os.environ.get("STEPS", "3"))):      # STEPS=80: the stampe
     plan.set_image_device(img.data_ptr())
     plan.convolve_packed_device(n, ker.data_ptr(), kh, kw, out.data_ptr())
 torch.cuda.synchronize()
-raw = dbg.cpu().numpy().reshape(16, 8)
+raw = dbg.cpu().numpy()[:128].reshape(16, 8)
 t = raw.astype(np.float64) / 100.0
 names = ["P1 fwd stage 1", "P2 fwd stage 2", "P3 stage 3 x S", "P4 inv stage 2", "P5 inv stage 1 + stores"]
 print("map    " + "  ".join("%24s" % s for s in names) + "   total")
