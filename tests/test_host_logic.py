@@ -371,6 +371,11 @@ def test_lds_bank_model_reproduces_the_documented_layout_of_cfg3():
     listed = re.findall(r"^    X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", hdr, flags=re.M)
     assert len(listed) >= 5
     configs = {tuple(int(x) for x in c.split()[:5]): int(c.split()[5]) for c in m.CONFIGS.replace("\n", " ").split(";")}
+    # the tool's configuration list is the header's (fast_paths.hpp: FC_FAST_COL_CONFIGS_G0 / _G1)
+    fp = open(os.path.join(util.ROOT, "cuda-fft-convolution_amd", "csrc", "fast_paths.hpp")).read()
+    cols = fp[fp.index("#define FC_FAST_COL_CONFIGS_G0(X)"):fp.index("#define FC_FAST_COL_CONFIGS(X)")]
+    in_header = {tuple(int(x) for x in mm) for mm in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", cols)}
+    assert in_header == {k + (v,) for k, v in configs.items()}, in_header ^ {k + (v,) for k, v in configs.items()}
     for ent in listed:
         M, R1, R2, R3, T, pad, rot = (int(x) for x in ent)
         assert (M, R1, R2, R3, T) in configs, ent                 # a configuration of fast_paths.hpp
