@@ -10,7 +10,7 @@
 #if defined(FC_COLS_DBG) || defined(FC_ROWSM_DBG) || defined(FC_COLS_TIMELINE) || defined(FC_ROWS_TIMELINE) || \
     defined(FC_ROWS_NO_FOLD) || defined(FC_COLS_SPLIT_GATHER) || defined(FC_COLS_NO_PREWAIT) || defined(FC_COLS_PAIR_TRANSPOSE) || defined(FC_NT_SLOADS) ||              \
     defined(FC_NT_STORES) || defined(FC_NT_LOADS) || defined(FC_NO_PACKED) || defined(FC_MULTIF_S_EARLY) || defined(FC_ROWS_NO_BLOCK_PAD) || \
-    defined(FC_COLS_NO_BLOCK_PAD) || defined(FC_ROWS_STAGGER_TICKS) || defined(FC_ROWS_STAGGER_RAMP) || defined(FC_ROWS_PAIR)
+    defined(FC_COLS_NO_BLOCK_PAD) || defined(FC_ROWS_STAGGER_TICKS) || defined(FC_ROWS_STAGGER_RAMP)
 #error "kernel instrumentation switches need -DFC_INSTRUMENT (diagnostic builds only; the product never sets them)"
 #endif
 #endif
@@ -47,9 +47,6 @@
 #endif
 #ifndef FC_ROWS_NO_BLOCK_PAD
 #define FC_ROWS_NO_BLOCK_PAD 0   // 1: the stage-1 blocks of a row m1 cells apart in LDS (no padding against the stage-2 bank conflicts; A/B)
-#endif
-#ifndef FC_ROWS_PAIR
-#define FC_ROWS_PAIR 0           // 1 (experiment): F = 1 row launches of the one-row configurations run as workgroups of two rows one phase apart (fast_rows_pair.hpp)
 #endif
 #ifndef FC_ROWS_STAGGER_TICKS
 #define FC_ROWS_STAGGER_TICKS 0  // > 0 (experiment, needs plan option timeline_ptr = a zeroed device buffer of 4096 ints): the k-th workgroup of the launch's first round

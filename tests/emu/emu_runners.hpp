@@ -5,9 +5,6 @@
 #include <vector>
 
 #include "pipeline.hpp"
-#if FC_ROWS_PAIR
-#include "fast_rows_pair.hpp"
-#endif
 
 namespace emu {
 using namespace fc;
@@ -67,18 +64,6 @@ struct EmuFastRows {
                     if (linear) fast_rows_multi_body<Cfg, NZ2, true, true>(ctx, lds, b, grp, 0, group, rows);
                     else if constexpr (!ALWAYS_LINEAR) fast_rows_multi_body<Cfg, NZ2, false, true>(ctx, lds, b, grp, 0, group, rows);
                 } else {
-#if FC_ROWS_PAIR
-                    // experiment (fast_rows_pair.hpp): the one-row configurations as workgroups of two rows one phase apart
-                    if constexpr (Cfg::RPW == 1 && 2 * Cfg::NT <= 1024) {
-                        if (grp % 2 == 0) {
-                            for (int i = 0; i < 2 * Cfg::LR + Cfg::T2N; i++) lds[i] = mk(1e30f, -1e30f);
-                            HostPhaseCtx<RowMultiState<Cfg>> pctx(2 * Cfg::NT);
-                            if (linear) fast_rows_pair_body<Cfg, NZ2, true>(pctx, lds, b, grp / 2, 0, group, rows);
-                            else if constexpr (!ALWAYS_LINEAR) fast_rows_pair_body<Cfg, NZ2, false>(pctx, lds, b, grp / 2, 0, group, rows);
-                        }
-                        continue;
-                    }
-#endif
                     HostPhaseCtx<RowMultiState<Cfg>> ctx(Cfg::NT);
                     if (linear) fast_rows_multi_body<Cfg, NZ2, true>(ctx, lds, b, grp, 0, group, rows);
                     else if constexpr (!ALWAYS_LINEAR) fast_rows_multi_body<Cfg, NZ2, false>(ctx, lds, b, grp, 0, group, rows);
