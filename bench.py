@@ -22,8 +22,9 @@ per-rank placement tuning, the broadcast step and the timing / check reductions 
 
 The steps themselves live in cuda-fft-convolution_amd/multi_gpu.py (shared with the tests).
 
-Untimed set-up and warm-up: the headline runs on DEFAULT plan options (round 5; rounds 2-4 had the plan time candidate
-allocations of its intermediate, plan option tune_placement -- that plan is now the extra `value_tuned_placement`); the W warm-up
+Untimed set-up and warm-up: the headline runs on DEFAULT plan options (round 5).  The library's default for plan option tune_placement is
+automatic: a plan whose launches write >= 2 GiB of maps on a mostly free device times five candidate allocations of its intermediate at its
+first convolve (~100 ms, inside the warm-up); the other policy runs beside it as `value_untuned_placement` / `value_tuned_placement`; the W warm-up
 steps are followed by more untimed steps where they are shorter than the ~40 ms the GPU's clocks
 need to settle after an idle gap (config.clock_warm_steps).  The timed region is exactly K steps.
 
@@ -535,10 +536,12 @@ def main():
     ap.add_argument("--weak", action="store_true", help="--filters (or the config's count) is per GPU: weak scaling")
     ap.add_argument("--batch-maps", type=int, default=0)
     ap.add_argument("--kernel-chunk-mb", type=int, default=0, help="budget of the kernels' column-spectrum chunk (0 = the library's default; A/B)")
-    ap.add_argument("--tune-placement", type=int, default=0,
+    ap.add_argument("--tune-placement", type=int, default=-1,
                     help="candidate allocations of the intermediate the plan times against the map buffer (plan option "
-                         "tune_placement).  0 = off = the library's default and, since round 5, the headline's; where a launch covers "
-                         ">= 5e8 padded pixels the line carries `value_tuned_placement` (a second plan with 5 candidates) beside it")
+                         "tune_placement).  -1 = the library's default = the headline's: automatic (five candidates where a launch writes "
+                         ">= 2 GiB of maps and the device is mostly free); 0 = never.  Where a launch covers >= 5e8 padded pixels the line "
+                         "carries the other policy beside it: `value_untuned_placement` (a second plan with tune_placement = 0) beside a "
+                         "plan that tuned, `value_tuned_placement` (5 candidates) beside one that did not")
     ap.add_argument("--rows-group", type=int, default=0, help="maps per workgroup of the spectral-row kernel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
@@ -697,10 +700,10 @@ def main():
     # placement tuning (untimed set-up, like a plan's measuring) is OFF for the headline since round 5: `value` is what a caller with
     # default plan options gets.  Where launches are long enough to tell 4 % apart a second, tuned plan (5 candidates) is timed beside
     # it (`value_tuned_placement`).
-    tune_k = max(0, args.tune_placement)
-    if tune_k > 1:
+    tune_k = args.tune_placement
+    if tune_k >= 0:
         plan.set_option("tune_placement", tune_k)
-    tuned_beside = 5 if (tune_k <= 1 and min(args.batch_maps or 64, max(nf, 1)) * P >= 5e8) else 0
+    other_policy_beside = min(args.batch_maps or 64, max(nf, 1)) * P >= 5e8
     # a side stream only where something overlaps: the next step's transform + broadcast (N > 1), or
     # the next image's H2D copy (streamed mode)
     overlap = streamed or ((use_dist or args.overlap or side_work is not None) and not args.no_overlap)
@@ -916,19 +919,20 @@ def main():
             dt_r = timed(lambda k: conv_r.run([img_d] * k), args.steps)
             extras["ms_per_step_kernels_resident"] = dt_r / args.steps * 1e3
             extras["value_kernels_resident"] = nf_total * P * args.steps / dt_r / 1e9
-        if tune_k > 1 or tuned_beside:
-            # the other placement policy on the same maps: default options beside a tuned headline, a tuned plan beside the default one
+        main_tuned = plan.get_option("tuned_candidates") > 1
+        if other_policy_beside:
+            # the other placement policy on the same maps: an untuned plan beside one that tuned, a tuned plan (5 candidates) beside one that did not
+            tuned_beside = 0 if main_tuned else 5
             plan2 = fc.Plan(H, W, F, kh, kw, gpuId=local_rank, stream=stream.cuda_stream, options=plan_opts)
             if args.batch_maps:
                 plan2.set_option("batch_maps", args.batch_maps)
-            if tuned_beside:
-                plan2.set_option("tune_placement", tuned_beside)
+            plan2.set_option("tune_placement", tuned_beside)
             eng2 = mg.HipPlanEngine(torch, fc, plan2, dev, kern_d, kh, kw, first=first, main_stream=stream, overlap=overlap, out=out,
                                     defer_prepare=defer_prepare, kernels_host=kern_pin)
             conv2 = mg.FilterShardedConvolver(eng2, None, rank, world, nf_total, src=0, depth=2 if overlap else 1)
             conv2.run([img_d] * max(2, args.warmup))
             dt2 = timed(lambda k: conv2.run([img_d] * k), args.steps)
-            key = "tuned_placement" if tuned_beside else "default_options"
+            key = "tuned_placement" if tuned_beside else "untuned_placement"
             extras["value_" + key] = nf_total * P * args.steps / dt2 / 1e9
             extras["ms_per_step_" + key] = dt2 / args.steps * 1e3
             if tuned_beside:
@@ -1025,7 +1029,9 @@ def main():
                                       else "double-buffered on an upload stream")) if upload_kernels
                                   else "resident in HBM",
                        "hip_graph_replay": bool(args.graph), "clock_warm_steps": clock_warm_steps, "settle_s": args.settle_s,
-                       "tune_placement": {"candidates": plan.get_option("tuned_candidates"), "kept": plan.get_option("tuned_best")} if tune_k > 1 else None,
+                       "tune_placement": ({"option": plan.get_option("tune_placement"), "candidates": plan.get_option("tuned_candidates"),
+                                           "kept": plan.get_option("tuned_best")} if plan.get_option("tuned_candidates") > 1
+                                          else {"option": plan.get_option("tune_placement"), "candidates": 0}),
                        "dynamic_tiles": plan.get_option("dynamic_tiles"),
                        "contention": hog_cfg,
                        "images_per_step": args.images if streamed else 1,

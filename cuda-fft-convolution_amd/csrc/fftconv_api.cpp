@@ -177,10 +177,12 @@ int run_group_impl(fftconv_plan* p, int n, const float* dk, int kh, int kw, cons
     if (streamed)
         if (int rc = ring_ensure(p)) return rc;
     if (p->Y.fresh) {   // before anything is written into it: the tuner may keep another allocation
-        if (p->opt_tune_placement > 1 && !win) {
+        int tune_k = (int)p->opt_tune_placement;
+        if (tune_k < 0) tune_k = win ? 0 : placement_auto_candidates(p, (size_t)std::min(nbY, n) * g.map_elems() * sizeof(float));
+        if (tune_k > 1 && !win) {
             const bool direct = !cropped && !staged;   // the output kernel writes straight into the caller's packed buffer
             float* first_obase = cropped ? p->O.p : (staged ? stage.p : sink.packed);
-            if (int rc = tune_intermediate_placement(p, direct ? n : std::min(nbY, n), nbY, first_obase, direct ? oe : 0)) return rc;
+            if (int rc = tune_intermediate_placement(p, tune_k, direct ? n : std::min(nbY, n), nbY, first_obase, direct ? oe : 0)) return rc;
         }
         p->Y.fresh = false;
     }
@@ -836,7 +838,7 @@ int fftconv_plan_set_option(fftconv_plan* plan, const char* name, long value) {
         if (!strcmp(name, "verbose")) plan->opt_verbose = value != 0;
         return fftconv_plan_set_option(plan->tiled->sub, name, value);
     }
-    if (!strcmp(name, "tune_placement")) { plan->opt_tune_placement = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }
+    if (!strcmp(name, "tune_placement")) { plan->opt_tune_placement = value < 0 ? -1 : (value > 8 ? 8 : value); return 0; }
     if (!strcmp(name, "kernel_chunk_mb")) { plan->opt_kernel_chunk_mb = value < 0 ? 0 : value; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
     if (!strcmp(name, "batch_maps")) { plan->opt_batch_maps = value < 0 ? 0 : value; plan->prepared.dk = nullptr; plan->deferred.on = false; return 0; }
     if (!strcmp(name, "profile")) {

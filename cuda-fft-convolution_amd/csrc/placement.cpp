@@ -1,9 +1,23 @@
-// placement.cpp -- opt-in placement tuning of a plan's intermediate (plan option tune_placement).
+// placement.cpp -- placement tuning of a plan's intermediate (plan option tune_placement; automatic for large launches on a mostly free device).
 #include "plan_internal.hpp"
 
 namespace fc {
 
-// Opt-in placement tuning of the intermediate (option tune_placement = k > 1).  On this memory system the
+// Option tune_placement left alone (-1): how many candidates the first convolve of a fresh intermediate tries.  Tuning pays where a launch is long
+// enough for 3 % of the output kernel to matter and costs ~100 ms plus transient allocations, so: launches that write at least 2 GiB of maps (cfg3 and
+// cfg4's share: 4.6 GB; cfg5, cfg2, cfg1: never) on a device that is at least 60 % free at that moment (a process that has the GPU to itself; several
+// processes sharing one device -- the rehearsals of the N > 1 tests -- stop tuning as soon as the others' buffers are there), five candidates.  Why a
+// default: which state an untuned plan gets is a property of the box -- six of six fresh processes slow on one (369 against 373.5 Gpixel-filters/s at
+// cfg3), five of six fast on another (profiles/r05q_default_vs_tuned_final_library*.txt).
+int placement_auto_candidates(const fftconv_plan* p, size_t launch_map_bytes) {
+    if (!p->g.fast_cols.ok || launch_map_bytes < ((size_t)2 << 30)) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (free_b < total_b / 10 * 6) return 0;
+    return 5;
+}
+
+// Placement tuning of the intermediate (option tune_placement = k > 1, or the automatic choice above).  On this memory system the
 // output kernel runs in one of two states, 4 % apart, and WHICH physical allocations hold the intermediate
 // and the maps decides it (profiles/r02x_placement_class_map.txt); nothing in user space can
 // ask for the fast pairing, but it can be found: right after the intermediate was (re)allocated, up to k
@@ -12,11 +26,10 @@ namespace fc {
 // freed.  The probes write into `out`, which the convolve that follows overwrites; they read the candidates as
 // allocated (the driver hands out zeroed memory).  Blocking (~70 ms), once per allocation: what FFTW calls
 // measuring at plan time.
-int tune_intermediate_placement(fftconv_plan* p, int n, int nbY, float* out, size_t out_stride_per_map) {
+int tune_intermediate_placement(fftconv_plan* p, int k, int n, int nbY, float* out, size_t out_stride_per_map) {
     // (out_stride_per_map > 0: the call's batches write to out + first_map * stride, and every batch's
     // destination is probed -- an 18-GB map buffer spans several placement regions; 0: one staging buffer)
     const Geometry& g = p->g;
-    const int k = (int)p->opt_tune_placement;
     p->Y.fresh = false;
     if (k < 2 || !g.fast_cols.ok || n < 1) return 0;
     {   // the tuner synchronises and frees: not inside a stream capture (the first convolve of a graph keeps its allocation)

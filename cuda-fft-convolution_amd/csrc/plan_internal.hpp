@@ -213,7 +213,8 @@ struct fftconv_plan {
     long opt_batch_maps = 0;
     long opt_kernel_chunk_mb = 0;
     int tuned_candidates = 0, tuned_best = 0;   // of the last placement tuning (fftconv_plan_get_option)
-    long opt_tune_placement = 0;   // > 1: that many candidate allocations of the intermediate are tried (tune_intermediate_placement)
+    long opt_tune_placement = -1;  // > 1: that many candidate allocations of the intermediate are tried (tune_intermediate_placement); 0 / 1: never;
+                                   // -1 (default): automatic -- placement_auto_candidates (placement.cpp)
     long opt_host_stream = 1;      // copy-out of host maps: 0 blocking, 1 direct by host threads, 2 pinned ring
     long opt_host_min_kb = FC_HOST_MIN_KB;   // maps smaller than this leave by blocking copies whatever host_stream says
     long opt_host_threads = 0;     // host copy threads of the output ring (0 = auto)
@@ -336,7 +337,8 @@ int ring_ensure(fftconv_plan* p);
 int ring_drain(fftconv_plan* p, const Sink& sink, int first, int count, int buf, const float* staging);
 
 // ---- placement tuning (placement.cpp) ----
-int tune_intermediate_placement(fftconv_plan* p, int n, int nbY, float* out, size_t out_stride_per_map);
+int tune_intermediate_placement(fftconv_plan* p, int k, int n, int nbY, float* out, size_t out_stride_per_map);
+int placement_auto_candidates(const fftconv_plan* p, size_t launch_map_bytes);
 
 // ---- block-wise plans (blockwise.cpp) ----
 bool blocks_preferred(const Geometry& g, const fftconv_plan_options* options);

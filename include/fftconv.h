@@ -307,10 +307,14 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             time, right before the row kernel reads them; > 0: as many launches' worth as fit that many MiB),
  *          "tune_placement" (k > 1: the next time the intermediate buffer is (re)allocated, k candidate
  *             allocations of it are timed with the output kernel writing into the caller's map buffer and
- *             the fastest is kept -- on MI355X the output kernel runs 4 % faster or slower depending on which
- *             physical allocations hold its two buffers; blocking, ~70 ms, once per
+ *             the fastest is kept -- on MI355X the output kernel runs 3-4 % faster or slower depending on which
+ *             physical allocations hold its two buffers; blocking, ~70-100 ms, once per
  *             allocation; transient device memory while it runs: k intermediates plus k - 1 spacer allocations of at
- *             most 12 GiB (an eighth of what is free) each; skipped inside a stream capture; 0 (default): off),
+ *             most 12 GiB (an eighth of what is free) each; skipped inside a stream capture and on plans with an output
+ *             window (the blocks of a block-wise plan); 0: never; -1 (default): automatic -- five candidates where a launch
+ *             writes at least 2 GiB of maps (BASELINE cfg3 / cfg4) AND at least 60 % of the device's memory is free at that
+ *             moment, nothing otherwise.  Which state an untuned plan lands in is a property of the machine's allocation order:
+ *             profiles/r05q_default_vs_tuned_final_library*.txt),
  *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
  *          "dynamic_tiles" (1, the default for transforms of 864 points and more along h (M >= 432): the persistent workgroups of
  *             the output kernel take their tiles from a queue in device memory -- one counter per XCD, chunks of adjacent tiles,

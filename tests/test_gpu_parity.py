@@ -229,7 +229,7 @@ def test_placement_tuning_keeps_results(fc, oracle):
     ref = oracle.conv_fft(img, kh, kw, ks)
     k_d = torch.from_numpy(np.ascontiguousarray(np.stack([np.transpose(k, (2, 1, 0)) for k in ks]))).to(dev)
     with fc.Plan(H, W, F, kh, kw) as p:
-        assert p.get_option("tune_placement") == 0 and p.get_option("tuned_candidates") == 0
+        assert p.get_option("tune_placement") == -1 and p.get_option("tuned_candidates") == 0      # -1: automatic (large launches only)
         p.set_option("tune_placement", 3)
         p.set_option("batch_maps", 2)            # three launches per call: every batch's destination is probed
         p.set_image(img)
@@ -253,6 +253,45 @@ def test_placement_tuning_keeps_results(fc, oracle):
         assert p.get_option("tuned_candidates") == 2
         for g, r in zip(got, ref):
             assert util.rel_err(g, r) < TIGHT
+
+
+def test_placement_tuning_is_automatic_for_large_launches_only(fc):
+    """tune_placement left at its default (-1): a plan whose launches write 2 GiB of maps and more tunes at its first convolve when the
+    device is mostly free (csrc/placement.cpp: placement_auto_candidates), a small plan never does, and 0 switches it off; the maps are
+    the same either way (bit-exact: the candidates differ in where the intermediate lies, not in what is computed)"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    H = W = 4096
+    kh = kw = 63
+    n = 40                                        # 40 maps of 4160 x 4160 floats = 2.8 GB per launch
+    g = torch.Generator(device="cpu").manual_seed(5)
+    img = torch.rand((1, W, H), generator=g, dtype=torch.float32).to(dev)
+    ker = torch.rand((n, 1, kw, kh), generator=g, dtype=torch.float32).to(dev)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    outs = []
+    for opt in (None, 0):
+        with fc.Plan(H, W, 1, kh, kw) as p:
+            if opt is not None:
+                p.set_option("tune_placement", opt)
+            out = torch.empty((n, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+            p.set_image_device(img.data_ptr())
+            p.convolve_packed_device(n, ker.data_ptr(), kh, kw, out.data_ptr())
+            p.synchronize()
+            tuned = p.get_option("tuned_candidates")
+            if opt == 0:
+                assert tuned == 0
+            elif free_b >= 0.7 * total_b:         # (a device that other processes fill is allowed to skip it)
+                assert tuned == 5 and 0 <= p.get_option("tuned_best") < 5
+            outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    with fc.Plan(1024, 1024, 1, 63, 63) as p:     # 16 maps of 1088 x 1088: 76 MB per launch
+        k16 = torch.rand((16, 1, 63, 63), dtype=torch.float32, device=dev)
+        i16 = torch.rand((1, 1024, 1024), dtype=torch.float32, device=dev)
+        out = torch.empty((16, p.info.fft_w, p.info.fft_h), dtype=torch.float32, device=dev)
+        p.set_image_device(i16.data_ptr())
+        p.convolve_packed_device(16, k16.data_ptr(), 63, 63, out.data_ptr())
+        p.synchronize()
+        assert p.get_option("tuned_candidates") == 0
 
 
 def test_external_spectrum_buffer_roundtrip(fc, oracle):

@@ -10,5 +10,5 @@ bash tools/profile_round.sh $TAG ${COMMIT:-unknown} > gpurun_out/${TAG}_profile_
 python - <<PY
 import json
 j=json.loads(open('gpurun_out/prof_$TAG/bench.json').read().strip().splitlines()[-1])
-print('bench', round(j['value'],1), 'frac', round(j['roofline']['frac'],3), 'tuned beside', round(j.get('value_tuned_placement',0),1), 'resident', round(j.get('value_kernels_resident',0),1), 'cpu', round(j['cpu_baseline']['value'],4), j['cpu_baseline']['value_from'])
+print('bench', round(j['value'],1), 'frac', round(j['roofline']['frac'],3), 'other placement policy beside', round(j.get('value_untuned_placement', j.get('value_tuned_placement', 0)),1), j['config'].get('tune_placement'), 'resident', round(j.get('value_kernels_resident',0),1), 'cpu', round(j['cpu_baseline']['value'],4), j['cpu_baseline']['value_from'])
 PY
