@@ -226,8 +226,18 @@ int fftconv_convolution_fft_ex(const float* data, int data_h, int data_w, int fe
     const CacheKey key = cache_key(data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, options);
     fftconv_plan* p = cache_take(key);
     tm.cache_hit = p ? 1 : 0;
-    if (!p)
+    if (!p) {
         if (int rc = fftconv_plan_create_ex(&p, data_h, data_w, feature_dim, max_kernel_h, max_kernel_w, gpu_id, nullptr, options)) return rc;
+        // a plan that will not be kept (cache switched off: fftconv_cache_configure(0, ...)) has nothing to gain from timing candidate
+        // placements of its intermediate (~100 ms against ~1 % of one call): the automatic default (placement.cpp) is for plans that live on
+        bool kept;
+        {
+            PlanCache& c = plan_cache();
+            std::lock_guard<std::mutex> lk(c.m);
+            kept = c.max_plans > 0;
+        }
+        if (!kept) (void)fftconv_plan_set_option(p, "tune_placement", 0);
+    }
     (void)fftconv_plan_set_option(p, "verbose", options_verbose(options) ? 1 : 0);
     tm.plan_ms = ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();

@@ -313,7 +313,8 @@ int fftconv_plan_synchronize(fftconv_plan *plan);
  *             most 12 GiB (an eighth of what is free) each; skipped inside a stream capture and on plans with an output
  *             window (the blocks of a block-wise plan); 0: never; -1 (default): automatic -- five candidates where a launch
  *             writes at least 2 GiB of maps (BASELINE cfg3 / cfg4) AND at least 60 % of the device's memory is free at that
- *             moment, nothing otherwise.  Which state an untuned plan lands in is a property of the machine's allocation order:
+ *             moment, nothing otherwise (and never in a one-shot call whose plan is not kept: cache switched off).  It pays for itself after ~600
+ *             cfg3 steps (7 s of work on the plan).  Which state an untuned plan lands in is a property of the machine's allocation order:
  *             profiles/r05q_default_vs_tuned_final_library*.txt),
  *          "rows_group" (fftconv_plan_options.rows_group, changeable between calls),
  *          "dynamic_tiles" (1, the default for transforms of 864 points and more along h (M >= 432): the persistent workgroups of
