@@ -697,9 +697,9 @@ def main():
             elif hog_cfg["lds_kb"] > 8:
                 raise SystemExit("bench.py --contend: workgroups that hold more than 8 KB of LDS for the whole timed region would block "
                                  "the persistent kernels until the stop that follows them; give a per-step duration (K,LDS_KB,US)")
-    # placement tuning (untimed set-up, like a plan's measuring) is OFF for the headline since round 5: `value` is what a caller with
-    # default plan options gets.  Where launches are long enough to tell 4 % apart a second, tuned plan (5 candidates) is timed beside
-    # it (`value_tuned_placement`).
+    # placement tuning: `value` is what a caller with DEFAULT plan options gets -- the library's automatic choice (large launches on a free
+    # device tune at their first convolve, inside the warm-up; placement.cpp).  Where launches are long enough to tell 3 % apart the other
+    # policy is timed beside it (`value_untuned_placement`, or `value_tuned_placement` where the plan did not tune).
     tune_k = args.tune_placement
     if tune_k >= 0:
         plan.set_option("tune_placement", tune_k)
